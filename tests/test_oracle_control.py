@@ -1,0 +1,211 @@
+"""Pin the scalar control oracle to the reference: per-function golden I/O, the
+open-loop scheduler trace and the closed-loop trace produced by importing the
+reference (tests/golden/make_golden.py), plus the known answers of the reference's
+tests/unit/control/test_controller.py and tests/unit/quadrotor/test_quad.py."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import col_err, load_golden
+from oracle import control_oracle as co
+
+V = co.Vehicle()
+
+
+def test_gains_match_reference():
+    g = load_golden("controller_io.npz")["gains"]
+    ours = [V.kp_xy, V.kd_xy, V.kp_z, V.kd_z, V.ki_z, V.kp_roll, V.kp_pitch, V.kp_yaw, V.kp_p, V.kp_q, V.kp_r]
+    assert np.array_equal(np.array(ours), g)
+
+
+def test_wraps_match_reference():
+    g = load_golden("controller_io.npz")
+    for a, wp, w2 in zip(g["wraps_in"], g["wrap_pi"], g["wrap_2pi"]):
+        assert co.wrap_to_pi(a) == wp
+        assert co.wrap_to_2pi(a) == w2
+    # reference test_controller.py:24-50
+    assert co.wrap_to_pi(-3 * np.pi / 2) == pytest.approx(np.pi / 2)
+    assert co.wrap_to_pi(3 * np.pi / 2) == pytest.approx(-np.pi / 2)
+    assert co.wrap_to_2pi(-0.1) == pytest.approx(2 * np.pi - 0.1)
+
+
+def test_per_function_io_matches_reference():
+    g = load_golden("controller_io.npz")
+    n = len(g["X"])
+    out = {k: np.empty_like(g[k]) for k in ("R", "euler", "thrust", "integ1", "bxy", "pq", "pqr", "moment",
+                                            "forces", "omega_cmd", "omega1")}
+    for i in range(n):
+        u = co.UAV(V)
+        u.X = g["X"][i].copy()
+        u.integral = float(g["integ0"][i])
+        tgt = g["target"][i]
+        R = co.quat_to_rot(u.X[3:7])
+        out["R"][i] = R
+        out["euler"][i] = co.euler(u.X[3:7])
+        thrust = co.altitude(u, tgt[[2, 5, 8]], R)
+        out["thrust"][i] = thrust
+        out["integ1"][i] = u.integral
+        bxy = co.lateral(u, tgt[[0, 3, 6]], tgt[[1, 4, 7]], thrust)
+        out["bxy"][i] = bxy
+        p_c, q_c = co.roll_pitch(V, bxy, R)
+        out["pq"][i] = (p_c, q_c)
+        out["pqr"][i] = (p_c, q_c, co.yaw_rate(V, u.X[3:7], tgt[9], q_c))
+        u.pqr_cmd = g["pqr_cmd_in"][i].copy()
+        mom = co.body_rate(u)
+        out["moment"][i] = mom
+        out["forces"][i] = co.allocate(V, g["thrust_in"][i], mom)
+        u.omega = g["omega0"][i].copy()
+        co.set_propeller_speed(u, g["thrust_in"][i], mom)
+        out["omega_cmd"][i] = u.omega_cmd
+        out["omega1"][i] = u.omega
+    for k, v in out.items():
+        assert col_err(v, g[k]) < 1e-12, k
+    # every clip / branch of SURVEY.md 8(c)-5 is exercised by the fixture
+    assert (g["thrust"] == 0.4).any() and (g["thrust"] == 18.0).any()
+    assert (np.abs(g["bxy"]) == 0.7).any() and (np.abs(g["bxy"]) < 0.7).any()
+    assert (np.abs(g["integ1"]) == 10.0).any()
+    assert (g["forces"] == 0.1).any() and (g["forces"] == 4.5).any()
+
+
+def test_integral_clamp_sequence():
+    g = load_golden("controller_io.npz")["integral_sequence"]
+    u = co.UAV(V)
+    seq = []
+    for _ in range(len(g)):
+        co.altitude(u, np.array([5.0, 0.0, 0.0]), np.eye(3))
+        seq.append(u.integral)
+    assert np.allclose(seq, g, rtol=0, atol=1e-12)
+    assert max(np.abs(seq)) <= co.INTEGRAL_ERROR_LIMIT    # reference test_controller.py:136-146
+
+
+def test_reference_known_answers_controller():
+    u = co.UAV(V)
+    # hover thrust (test_controller.py:77-86)
+    assert co.altitude(u, np.array([0.0, 0.0, 0.0]), np.eye(3)) == pytest.approx(V.mass * V.g)
+    # climb / descent rate clipping equivalence (test_controller.py:89-120)
+    for big, lim in ((100.0, V.max_descent), (-100.0, -V.max_ascent)):
+        a = co.altitude(co.UAV(V), np.array([0.0, big, 0.0]), np.eye(3))
+        b = co.altitude(co.UAV(V), np.array([0.0, lim, 0.0]), np.eye(3))
+        assert a == pytest.approx(b)
+    # thrust bounds (test_controller.py:123-133)
+    t = co.altitude(co.UAV(V), np.array([-100.0, 0.0, 0.0]), np.eye(3))
+    assert 4 * V.min_thrust <= t <= 4 * V.max_thrust
+    # tilt saturation (test_controller.py:149-159)
+    b = co.lateral(co.UAV(V), np.array([100.0, 0, 0]), np.array([-100.0, 0, 0]), V.mass * V.g)
+    assert np.all(np.abs(b) <= V.max_tilt)
+    # body-rate moment (test_controller.py:162-183)
+    u = co.UAV(V)
+    u.pqr_cmd = np.array([1.0, 0.0, 0.0])
+    assert co.body_rate(u) == pytest.approx([V.inertia[0] * V.kp_p, 0.0, 0.0])
+    u.X[10:13] = [1.0, 2.0, 3.0]
+    u.pqr_cmd = u.X[10:13].copy()
+    I = np.array(V.inertia)
+    assert co.body_rate(u) == pytest.approx(np.cross(u.X[10:13], I * u.X[10:13]))
+
+
+def test_reference_known_answers_yaw():
+    # test_controller.py:186-212 feed phi/theta/psi directly; build quaternions that give them
+    def quat(phi, theta, psi):
+        cr, sr, cp, sp, cy, sy = (math.cos(phi / 2), math.sin(phi / 2), math.cos(theta / 2), math.sin(theta / 2),
+                                  math.cos(psi / 2), math.sin(psi / 2))
+        return np.array([cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy,
+                         cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy])
+    Vy = co.Vehicle()
+    Vy.kp_yaw = 2.0
+    assert co.yaw_rate(Vy, quat(0, 0, 0.1), -0.1, 0.0) == pytest.approx(2.0 * -0.2)
+    phi, theta, psi = 0.3, -0.2, 0.1
+    exp = (2.0 * (0.4 - psi) * math.cos(theta) - 0.5 * math.sin(phi)) / math.cos(phi)
+    assert co.yaw_rate(Vy, quat(phi, theta, psi), 0.4, 0.5) == pytest.approx(exp)
+
+
+def test_reference_known_answers_quad():
+    # test_quad.py:13-45
+    assert co.quat_to_rot([1, 0, 0, 0]) == pytest.approx(np.eye(3))
+    h = np.pi / 4
+    assert co.quat_to_rot([np.cos(h), 0, 0, np.sin(h)]) @ [1, 0, 0] == pytest.approx([0, 1, 0], abs=1e-12)
+    R = co.quat_to_rot([0.4, -0.3, 0.5, 0.2])
+    assert R.T @ R == pytest.approx(np.eye(3)) and np.linalg.det(R) == pytest.approx(1.0)
+    # test_quad.py:48-69
+    assert co.euler([np.cos(0.15), np.sin(0.15), 0, 0]) == pytest.approx((0.3, 0, 0))
+    assert co.euler([np.cos(0.6), 0, 0, np.sin(0.6)]) == pytest.approx((0, 0, 1.2))
+    # allocation (test_quad.py:72-140)
+    assert co.allocate(V, 2.0, np.zeros(3)).sum() == pytest.approx(2.0)
+    f = co.allocate(V, 4.0, np.array([0.2, 0, 0]))
+    assert V.arm * (f[0] + f[3] - f[1] - f[2]) == pytest.approx(0.2)
+    assert V.arm * (f[0] + f[1] - f[2] - f[3]) == pytest.approx(0.0, abs=1e-12)
+    f = co.allocate(V, 4.0, np.array([0, 0, 0.01]))
+    assert V.kappa * (-f[0] + f[1] - f[2] + f[3]) == pytest.approx(0.01)
+    f = co.allocate(V, 4.0, np.array([0, 0, 0.5]))
+    assert np.all(f >= V.min_thrust) and np.all(f <= V.max_thrust) and f.sum() == pytest.approx(4.0)
+    assert co.allocate(V, 100.0, np.zeros(3)) == pytest.approx(np.full(4, V.max_thrust))
+    # motor lag (test_quad.py:143-169)
+    u = co.UAV(V, hover=False)
+    co.set_propeller_speed(u, 4.0, np.zeros(3))
+    assert u.omega_cmd == pytest.approx(np.full(4, 1.0))
+    assert u.omega == pytest.approx(np.full(4, 1 - np.exp(-V.dt / V.tau_rise)))
+    u = co.UAV(V, hover=False)
+    w0 = np.sqrt(V.max_thrust)
+    u.omega = np.full(4, w0)
+    co.set_propeller_speed(u, 0.0, np.zeros(3))
+    assert u.omega == pytest.approx(np.full(4, w0 + (1 - np.exp(-V.dt / V.tau_fall)) * (np.sqrt(V.min_thrust) - w0)))
+
+
+def test_enu_to_ned_known_answer():
+    # reference tests/unit/simulation/test_mujoco_sim.py:61-74
+    s = co.mujoco_to_ned_state(np.array([1.0, -2.0, 3.0]), np.array([np.sqrt(0.5), 0, 0, np.sqrt(0.5)]),
+                               np.array([4.0, -5.0, 6.0, 0.1, -0.2, 0.3]))
+    assert s[:3] == pytest.approx([1, 2, -3])
+    assert s[3:7] == pytest.approx([np.sqrt(0.5), 0, 0, -np.sqrt(0.5)])
+    assert s[7:10] == pytest.approx([4, 5, -6])
+    assert s[10:13] == pytest.approx([0.1, 0.2, -0.3])
+
+
+def test_open_loop_scheduler_trace_matches_reference():
+    g = load_golden("open_loop.npz")
+    u = co.UAV(V)
+    u.X = g["X0"].copy()
+    log = np.empty_like(g["log"])
+    for k in range(len(log)):
+        co.controller_tick(u, g["traj"])
+        log[k] = np.concatenate([[u.thrust_cmd], u.pqr_cmd, u.omega_cmd, u.omega, [u.traj_index, u.integral]])
+    assert np.array_equal(log[:, 12], g["log"][:, 12])          # trajectory_index exact
+    assert col_err(log, g["log"]) < 1e-12
+
+
+@pytest.mark.parametrize("name, K", [("config1", 8000), ("lab_v2", 3000)])
+def test_closed_loop_trace_matches_reference(name, K):
+    g = load_golden("closed_loop.npz")
+    traj = g[name + "_traj"]
+    u = co.UAV(V, position=traj[0, 0:3])
+    slog, clog = co.rollout(u, traj, K)
+    assert col_err(slog[:200], g[name + "_state_first200"]) < 1e-10
+    assert col_err(clog[:200], g[name + "_cmd_first200"]) < 1e-10
+    n = K // 10
+    assert col_err(slog[9::10], g[name + "_state_every10"][:n]) < 1e-5
+    assert col_err(clog[9::10], g[name + "_cmd_every10"][:n]) < 1e-5
+
+
+def test_dynamics_invariants():
+    # hover: rotors at sqrt(mg/4kf) hold position (reference test_mujoco_sim.py:163-174 tolerance 1e-6)
+    u = co.UAV(V, position=(1.0, 7.0, -1.0))
+    for _ in range(100):
+        co.dynamics_step(u)
+    assert np.allclose(u.X[0:3], [1.0, 7.0, -1.0], atol=1e-6) and np.allclose(u.X[7:10], 0, atol=1e-6)
+    # free fall: rotors off -> z increases in NED (test_mujoco_sim.py:150-160), v = g t exactly for Euler
+    u = co.UAV(V, position=(0, 0, -10.0), hover=False)
+    for _ in range(100):
+        co.dynamics_step(u)
+    assert u.X[9] == pytest.approx(V.g * 0.1)
+    assert u.X[2] == pytest.approx(-10.0 + V.g * 0.001 ** 2 * (100 * 101 / 2))
+    assert u.X[3:7] == pytest.approx([1, 0, 0, 0])
+
+
+def test_closed_loop_meets_reference_integration_bounds():
+    # reference tests/integration/test_mujoco_trajectory_tracking.py:34-36 (<0.5 m final, <0.5 m mean)
+    g = load_golden("closed_loop.npz")
+    traj = g["lab_v2_traj"]
+    s = g["lab_v2_state_every10"]
+    n = min(len(traj), len(s))
+    err = np.linalg.norm(s[:n, 0:3] - traj[:n, 0:3], axis=1)
+    assert err.mean() < 0.5 and np.linalg.norm(s[-1, 0:3] - traj[-1, 0:3]) < 0.5
