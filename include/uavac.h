@@ -1,0 +1,184 @@
+/*
+ * uavac.h -- C ABI of libuavac.so: batched minimum-snap planning and cascaded
+ * control + 6-DoF rollout for fleets of independent quadrotors on AMD MI355X
+ * (gfx950).  Hand-written HIP kernels behind plain pointers and sizes.
+ *
+ * The reference (Mdhvince/UAV-Autonomous-control) has no FFI layer: its boundary
+ * is a set of Python classes.  Each entry point below names the reference
+ * interface it replaces (paths relative to the upstream repository root); the
+ * Python binding a maintainer adds on the reference side is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all floating point is IEEE fp64; NED world frame, FRD body frame;
+ *   - every function returns UAVAC_OK (0) or a negative UAVAC_E* code; the text
+ *     of the last failure is available from uavac_last_error(ctx);
+ *   - a ctx owns one HIP stream (or borrows the caller's, see
+ *     uavac_set_stream) and is not thread-safe; distinct ctxs are independent;
+ *   - functions with the _dev suffix take DEVICE pointers, enqueue on the ctx
+ *     stream and return without synchronising; the un-suffixed twins take HOST
+ *     pointers, stage through device scratch and are synchronous on return;
+ *   - nothing here ever falls back to a CPU path: without a usable GPU
+ *     uavac_create fails with UAVAC_EHIP.
+ */
+#ifndef UAVAC_H
+#define UAVAC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVAC_VERSION 100 /* 0.1.0 */
+
+#define UAVAC_OK 0
+#define UAVAC_EINVAL (-1)    /* bad shape / size / null pointer                    */
+#define UAVAC_ENONFINITE (-2)/* non-finite waypoint, velocity or dt                */
+#define UAVAC_EHIP (-3)      /* HIP runtime error (text in uavac_last_error)       */
+#define UAVAC_ESINGULAR (-4) /* a mission's knot system is singular (e.g. repeated waypoint) */
+#define UAVAC_ENOMEM (-5)
+
+#define UAVAC_MAX_SEGMENTS 64   /* m, segments per mission                          */
+#define UAVAC_TRAJ_COLS 11      /* x y z vx vy vz ax ay az yaw spline_id: minimum_snap.py:122-123 */
+#define UAVAC_STATE_ROWS 26     /* see uavac_control_* below                        */
+#define UAVAC_ISTATE_ROWS 3
+#define UAVAC_CMD_COLS 12
+
+typedef struct uavac_ctx uavac_ctx;
+
+/* Vehicle constants, limits and controller gains.
+ * Replaces the attributes of uav_ac/quadrotor/quad.py:11-86 (Quad.__init__) that the
+ * controller reads, with the values models/lab_course.xml:3,9-13,100,116 provides. */
+typedef struct uavac_vehicle {
+    double g;               /* gravity [m/s^2]                      quad.py:39  */
+    double dt;              /* inner (dynamics / motor) step [s]    quad.py:40  */
+    double dt_outer;        /* CascadedController.dt = dt * inner_per_outer  main.py:97-98 */
+    double mass;
+    double inertia[3];      /* diagonal body inertia                */
+    double arm;             /* roll/pitch lever arm of each rotor   */
+    double kf;              /* rotor speed^2 -> thrust coefficient  */
+    double kappa;           /* rotor reaction torque / thrust       */
+    double min_thrust, max_thrust;      /* per rotor [N]             */
+    double tau_rise, tau_fall;          /* motor time constants [s]  */
+    double max_ascent, max_descent, max_speed_xy, max_horiz_accel, max_tilt; /* flight_limits */
+    double kp_xy, kd_xy, kp_z, kd_z, ki_z;                /* quad.py:65-67 */
+    double kp_roll, kp_pitch, kp_yaw, kp_p, kp_q, kp_r;   /* quad.py:68-73 */
+    int32_t inner_per_outer;            /* config.ini:2 `frequency`  */
+    int32_t reserved;
+} uavac_vehicle;
+
+/* ---- context ------------------------------------------------------------------ */
+int uavac_version(void);
+/* device_id < 0: use the current HIP device. */
+int uavac_create(uavac_ctx **out, int device_id);
+void uavac_destroy(uavac_ctx *ctx);
+const char *uavac_last_error(const uavac_ctx *ctx);
+/* Borrow a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the ctx-owned stream. */
+int uavac_set_stream(uavac_ctx *ctx, void *hip_stream);
+int uavac_synchronize(uavac_ctx *ctx);
+/* Fill *V with the laboratory vehicle (lab_course.xml) and the gains of quad.py:42-73. */
+void uavac_vehicle_default(uavac_vehicle *V);
+
+/* ---- planning -----------------------------------------------------------------
+ * Batched drop-in for uav_ac/planning/minimum_snap.py MinimumSnap._generate_trajectory
+ * (:97-124) on B independent missions of m segments each (obstacles=None path).
+ *
+ *   wp          [B][m+1][3]  waypoints
+ *   times       [B][m]       segment durations            (_generate_time_per_spline :311-321)
+ *   seg_rows    [B][m] i32   rows sampled per segment = len(np.arange(0, T, dt))    (:104)
+ *   row_offsets [B+1]  i64   exclusive prefix sum of the per-mission row totals
+ *   coeffs      [B][8m][3]   polynomial coefficients, ascending powers, per spline  (:153)
+ *   traj        [row_offsets[B]][11]  rows of all missions back to back (:122-123)
+ */
+int uavac_minsnap_row_counts_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity,
+                                 double dt, double *times, int32_t *seg_rows, int64_t *row_offsets);
+/* Solves the joint minimum-snap QP of _compute_spline_parameters (:138-153) per mission.
+ * status [B] i32 (may be NULL): 0 ok, 1 singular system. */
+int uavac_minsnap_solve_dev(uavac_ctx *ctx, const double *wp, const double *times, int B, int m,
+                            double *coeffs, int32_t *status);
+/* Sampler (:100-119) + yaw scan (_calculate_yaws :126-136). */
+int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
+                             const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
+                             double dt, double *traj);
+
+/* Host-pointer twins (synchronous). */
+int uavac_minsnap_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity,
+                             double dt, double *times, int32_t *seg_rows, int64_t *row_offsets);
+int uavac_minsnap_solve(uavac_ctx *ctx, const double *wp, int B, int m, double velocity,
+                        double *coeffs, double *times);
+int uavac_minsnap_sample(uavac_ctx *ctx, const double *coeffs, const double *times, int B, int m,
+                         double dt, const int64_t *row_offsets, double *traj);
+
+/* ---- control ------------------------------------------------------------------
+ * Batched drop-in for one tick of uav_ac/main.py TrajectoryController.step (:37-61)
+ * [CascadedController: uav_ac/control/controller.py:26-168; rotor allocation and motor
+ * lag: uav_ac/quadrotor/quad.py:88-122] followed by MujocoSimulation.step
+ * (uav_ac/simulation/mujoco_sim.py:144-151) restricted to free flight (rotor wrench
+ * :232-251 + semi-implicit Euler free-body step; no contacts).
+ *
+ * State is struct-of-arrays over the batch (lane b = UAV b):
+ *   state  [26][B] f64: rows 0-12  X = x y z | q0 q1 q2 q3 | vx vy vz | p q r   (quad.py:75-80)
+ *                       rows 13-16 omega, rows 17-20 omega_command               (quad.py:83-86)
+ *                       row  21    altitude integral error                       (controller.py:20)
+ *                       row  22    thrust_cmd, rows 23-25 pqr_cmd                (main.py:26-27)
+ *   istate [3][B]  i32: trajectory_index, inner_step (main.py:24-25), collided (sticky flag)
+ *   traj / row_offsets: as produced by uavac_minsnap_sample (UAV b follows mission b).
+ */
+/* X = [position, identity attitude, rest]; rotors at hover speed if hover != 0, else 0;
+ * controller memory cleared (TrajectoryController.reset, main.py:29-35).
+ * positions [B][3] may be NULL (origin). */
+int uavac_state_init_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *positions, int B,
+                         int hover, double *state, int32_t *istate);
+/* K ticks fused in one launch.  state_log [K][13][B] (X after every tick) or NULL;
+ * cmd_log [K][12][B] (thrust_cmd, pqr_cmd, omega_command, omega after the controller part
+ * of every tick) or NULL; aabbs [n_obs][6] = xmin xmax ymin ymax zmin zmax (inclusive test of
+ * minimum_snap.py:327-357, evaluated on the position after every tick) or NULL. */
+int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
+                              const int64_t *row_offsets, double *state, int32_t *istate, int B,
+                              int K, double *state_log, double *cmd_log, const double *aabbs,
+                              int n_obs);
+/* One tick (K = 1, no logs): the literal drop-in of tc.step() + simulation.step(). */
+int uavac_control_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
+                           const int64_t *row_offsets, double *state, int32_t *istate, int B);
+
+/* Host-pointer twins (synchronous). */
+int uavac_state_init(uavac_ctx *ctx, const uavac_vehicle *V, const double *positions, int B,
+                     int hover, double *state, int32_t *istate);
+int uavac_control_rollout(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
+                          const int64_t *row_offsets, double *state, int32_t *istate, int B, int K,
+                          double *state_log, double *cmd_log, const double *aabbs, int n_obs);
+
+/* ---- per-function probes ------------------------------------------------------
+ * One stage of the control law at a time on small array-of-struct batches (host pointers,
+ * synchronous).  They run the very __device__ functions the fused rollout inlines, so the
+ * reference's unit-level known answers (tests/unit/control/test_controller.py,
+ * tests/unit/quadrotor/test_quad.py) can be replayed against the HIP path, and they back the
+ * single-UAV facade classes.  mask selects which optional inputs override computed values.
+ *
+ * outer: in [B][41] = X(13) | R(9) | target row(11) | integral | thrust_in | bxy_in(2) |
+ *                     euler_in(phi,theta,psi) | q_cmd_in
+ *        out[B][21] = R(9) [Quad.R, quad.py:129-155] | phi theta psi [quad.py:189-213] |
+ *                     thrust, integral' [altitude, controller.py:26-56] | bxy(2) [lateral :58-97] |
+ *                     p_c q_c [roll_pitch_controller :132-154] | pqr_cmd(3) [reduced_attitude :99-113]
+ * inner: in [B][24] = X(13) | pqr_cmd(3) | thrust_cmd | omega(4) | moment_in(3)
+ *        out[B][15] = moment(3) [body_rate_controller :115-130] | rotor forces(4)
+ *                     [_allocate_rotor_forces, quad.py:105-122] | omega_command(4), omega'(4)
+ *                     [set_propeller_speed, quad.py:88-103] */
+#define UAVAC_PROBE_OUTER_IN 41
+#define UAVAC_PROBE_OUTER_OUT 21
+#define UAVAC_PROBE_INNER_IN 24
+#define UAVAC_PROBE_INNER_OUT 15
+#define UAVAC_PROBE_USE_R 1       /* altitude / roll_pitch take the given rot_mat                */
+#define UAVAC_PROBE_USE_THRUST 2  /* lateral takes thrust_in instead of altitude's result        */
+#define UAVAC_PROBE_USE_BXY 4     /* roll_pitch takes bxy_in instead of lateral's result         */
+#define UAVAC_PROBE_USE_EULER 8   /* yaw_controller takes euler_in (duck-typed quad)             */
+#define UAVAC_PROBE_USE_QCMD 16   /* yaw_controller takes q_cmd_in instead of roll_pitch's q_c   */
+#define UAVAC_PROBE_USE_MOMENT 1  /* (inner) allocation takes moment_in instead of body_rate's   */
+int uavac_probe_outer(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out);
+int uavac_probe_inner(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVAC_H */

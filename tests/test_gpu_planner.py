@@ -1,0 +1,255 @@
+"""GPU parity of the HIP planner (K0 row counts, K1 solve, K2 sampler + yaw scan) against the
+reference's golden vectors and the CPU oracle.  Everything goes through the C ABI (ctypes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import col_err, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5      # north_star: <= 1e-5 relative on trajectory samples (SURVEY.md 8(c) metric)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from uav_ac.fleet import Engine
+    return Engine("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from uav_ac import _native as nat
+    return nat.Context(0)
+
+
+def host_plan(ctx, wps, velocity, dt):
+    """Plan through the host-pointer twins of the C ABI.  Returns coeffs, times, seg_rows, offsets, traj."""
+    from uav_ac import _native as nat
+    wps = nat.as_f64(wps)
+    B, m = wps.shape[0], wps.shape[1] - 1
+    times = np.empty((B, m))
+    seg_rows = np.empty((B, m), dtype=np.int32)
+    offs = np.empty(B + 1, dtype=np.int64)
+    ctx.call("uavac_minsnap_row_counts", nat.np_ptr(wps), B, m, velocity, dt, nat.np_ptr(times), nat.np_ptr(seg_rows),
+             nat.np_ptr(offs))
+    coeffs = np.empty((B, 8 * m, 3))
+    times2 = np.empty((B, m))
+    ctx.call("uavac_minsnap_solve", nat.np_ptr(wps), B, m, velocity, nat.np_ptr(coeffs), nat.np_ptr(times2))
+    assert np.array_equal(times, times2)
+    traj = np.empty((int(offs[-1]), 11))
+    ctx.call("uavac_minsnap_sample", nat.np_ptr(coeffs), nat.np_ptr(times), B, m, dt, nat.np_ptr(offs), nat.np_ptr(traj))
+    return coeffs, times, seg_rows, offs, traj
+
+
+@pytest.mark.parametrize("m", [1, 2, 8, 12, 20])
+def test_synthetic_missions_match_reference_golden(ctx, m):
+    g = load_golden("synthetic_missions.npz")
+    wps = g[f"m{m}_wp"]
+    coeffs, times, seg_rows, offs, traj = host_plan(ctx, wps, 3.0, 0.01)
+    assert np.allclose(times, g[f"m{m}_times"], rtol=1e-14, atol=0)
+    assert np.array_equal(seg_rows, g[f"m{m}_rows_per_segment"])          # row counts exact
+    assert col_err(coeffs.reshape(-1, 3), g[f"m{m}_coeffs_lstsq"].reshape(-1, 3)) < TOL
+    assert col_err(coeffs.reshape(-1, 3), g[f"m{m}_coeffs_solve"].reshape(-1, 3)) < 1e-9
+    sub = []
+    for b in range(len(wps)):
+        tr = traj[offs[b]:offs[b + 1]]
+        sub.append(tr[::16])
+        key = f"m{m}_traj{b}"
+        if key in g:
+            assert tr.shape == g[key].shape
+            assert np.array_equal(tr[:, 10], g[key][:, 10])               # spline ids exact
+            assert col_err(tr, g[key]) < TOL
+    assert col_err(np.vstack(sub), g[f"m{m}_traj_every16"]) < TOL
+
+
+def test_config1_and_lab_missions_match_reference_golden(ctx):
+    g = load_golden("fixed_missions.npz")
+    coeffs, times, _, offs, traj = host_plan(ctx, g["config1_wp"][None], 3.0, 0.01)
+    assert np.allclose(times[0], g["config1_times"], rtol=1e-14, atol=0)
+    assert traj.shape == (687, 11)
+    assert col_err(coeffs[0], g["config1_coeffs"]) < TOL
+    assert col_err(traj, g["config1_traj"]) < TOL
+    # lab mission without obstacles = takeoff (1 spline) + course (7 splines), main.py:73-84
+    lab = g["lab_wp"]
+    _, _, _, _, t0 = host_plan(ctx, lab[None, :2], 3.0, 0.01)
+    _, _, _, _, t1 = host_plan(ctx, lab[None, 1:], 3.0, 0.01)
+    both = np.vstack((t0, t1))
+    assert both.shape == g["lab_traj_free"].shape == (1076, 11)
+    assert col_err(both, g["lab_traj_free"]) < TOL
+    assert np.all(t0[:, 9] == 0.0)            # vertical takeoff: no valid heading -> zeros
+
+
+def test_device_pointer_path_equals_host_pointer_path(eng, ctx):
+    from oracle.minsnap_oracle import synthetic_missions
+    wps = synthetic_missions(96, 8)
+    plan = eng.plan(wps, 3.0, 0.01)
+    eng.check(plan)
+    coeffs, times, seg_rows, offs, traj = host_plan(ctx, wps, 3.0, 0.01)
+    assert np.array_equal(plan.row_offsets.cpu().numpy(), offs)
+    assert np.array_equal(plan.seg_rows.cpu().numpy(), seg_rows)
+    assert np.array_equal(plan.coeffs.cpu().numpy(), coeffs)          # deterministic: bit-identical
+    assert np.array_equal(plan.traj.cpu().numpy(), traj)
+    # a second run into the same buffers is bit-identical too
+    before = plan.traj.clone()
+    eng.solve(plan)
+    eng.sample(plan)
+    assert bool((plan.traj == before).all())
+
+
+@pytest.mark.parametrize("m, B", [(8, 512), (12, 256), (20, 128)])
+def test_against_oracle_on_fresh_missions(eng, m, B):
+    """Missions not in the golden set: HIP vs the oracle's exact (`solve`) KKT path."""
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(B, m)[-8:]
+    plan = eng.plan(wps, 3.0, 0.01)
+    for b in range(len(wps)):
+        ref = mo.plan(wps[b], 3.0, 0.01, method="solve")
+        got = plan.mission(b)
+        assert got.shape == ref.shape
+        assert col_err(got, ref) < 1e-8
+
+
+def test_stress_distribution_vs_exact_oracle(eng):
+    """segment lengths U(1,6) m -- compare with the oracle's LU (`solve`) path, where the
+    reference's own lstsq is no longer accurate to 1e-5."""
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(24, 12, lo=1.0, hi=6.0)
+    plan = eng.plan(wps, 3.0, 0.01)
+    for b in range(0, 24, 3):
+        ref = mo.plan(wps[b], 3.0, 0.01, method="solve")
+        got = plan.mission(b)
+        assert got.shape == ref.shape
+        assert col_err(got, ref) < 1e-6
+
+
+def _yaw_via_sampler(ctx, vel):
+    """Feed crafted velocities through the HIP yaw scan: one 1-row segment per sample, c1 = velocity."""
+    from uav_ac import _native as nat
+    n = len(vel)
+    coeffs = np.zeros((1, 8 * n, 3))
+    coeffs[0, 1::8, :] = vel
+    times = np.full((1, n), 0.005)
+    offs = np.array([0, n], dtype=np.int64)
+    traj = np.empty((n, 11))
+    ctx.call("uavac_minsnap_sample", nat.np_ptr(coeffs), nat.np_ptr(times), 1, n, 0.01, nat.np_ptr(offs), nat.np_ptr(traj))
+    assert np.array_equal(traj[:, 3:6], vel)
+    return traj[:, 9]
+
+
+@pytest.mark.parametrize("case", ["hold", "cross_pi", "none_valid", "exact_pi_steps", "leading_invalid"])
+def test_yaw_scan_crafted_cases(ctx, case):
+    g = load_golden("yaws.npz")
+    got = _yaw_via_sampler(ctx, g[case + "_vel"])
+    assert np.allclose(got, g[case + "_yaw"], rtol=0, atol=1e-12)
+
+
+def test_yaw_scan_random_spin_windows(ctx):
+    from oracle.minsnap_oracle import yaws_from_velocity
+    vel = load_golden("yaws.npz")["random_spin_vel"]
+    for lo in range(0, 400 - 64, 48):
+        w = vel[lo:lo + 64]
+        assert np.allclose(_yaw_via_sampler(ctx, w), yaws_from_velocity(w), rtol=0, atol=1e-11)
+
+
+def test_yaw_scan_across_chunks_and_late_first_valid(eng):
+    """A vertical first segment (> 256 rows: no usable heading for more than one chunk) followed by turns
+    that wrap through +-pi: exercises the back-fill and the carry of the unwrap sum across chunks."""
+    from oracle import minsnap_oracle as mo
+    wp = np.array([[[0, 0, 0], [0, 0, -12], [-3, 0.2, -12], [-6, -0.2, -12], [-3, -3, -12], [0, 0, -12],
+                    [-4, 0.1, -12], [-8, -0.1, -12]]], dtype=float)
+    plan = eng.plan(wp, 3.0, 0.01)
+    ref = mo.plan(wp[0], 3.0, 0.01, method="solve")
+    got = plan.mission(0)
+    assert got.shape == ref.shape and int(plan.seg_rows[0, 0]) > 256
+    assert np.ptp(ref[:, 9]) > np.pi                       # the unwrap really accumulates
+    assert np.allclose(got[:, 9], ref[:, 9], rtol=0, atol=1e-9)
+    assert col_err(got, ref) < 1e-8
+
+
+def test_yaw_backfill_when_first_heading_comes_after_several_chunks(ctx):
+    """Crafted coefficients through the sampler: 400 rows of purely vertical motion (no usable heading for
+    more than one 256-row chunk), then 900 rows whose heading winds several times: back-fill, hold and
+    the unwrap carry across chunks, against the oracle's sampler + yaw scan."""
+    from uav_ac import _native as nat
+    from oracle import minsnap_oracle as mo
+    coeffs = np.zeros((1, 24, 3))
+    coeffs[0, 1, 2] = -1.0                                     # segment 0: z' = -1, x' = y' = 0 exactly
+    t = np.arange(8)
+    coeffs[0, 8:16, 0] = [0, -1.0, 0.9, 0.4, -0.31, 0.05, -0.002, 0]      # segment 1: winding heading
+    coeffs[0, 8:16, 1] = [0, 0.02, -1.2, 0.5, 0.11, -0.06, 0.006, -0.0002]
+    coeffs[0, 16:24, 0] = [1, 1e-4, 0, 0, 0, 0, 0, 0]                      # segment 2: below the speed threshold
+    times = np.array([[4.0, 6.0, 3.0]])
+    offs = np.array([0, 400 + 600 + 300], dtype=np.int64)
+    traj = np.empty((1300, 11))
+    ctx.call("uavac_minsnap_sample", nat.np_ptr(coeffs), nat.np_ptr(times), 1, 3, 0.01, nat.np_ptr(offs), nat.np_ptr(traj))
+    pos, vel, acc, sid = mo.sample(coeffs[0], times[0], 0.01)
+    yaw = mo.yaws_from_velocity(vel)
+    assert np.ptp(yaw) > 2 * np.pi and np.all(yaw[:400] == yaw[400])   # winds; leading rows back-filled
+    assert np.allclose(traj[:, 9], yaw, rtol=0, atol=1e-10)
+    assert np.all(traj[1000:, 9] == traj[999, 9])                           # held through the slow tail
+    assert col_err(traj[:, 0:9], np.hstack((pos, vel, acc))) < 1e-12
+    assert np.array_equal(traj[:, 10], sid)
+
+
+def test_edge_shapes_and_errors(ctx, eng):
+    from uav_ac import _native as nat
+    # ragged batch: missions of very different lengths share one trajectory buffer
+    wps = np.array([[[0, 0, 0], [0.3, 0, 0], [0.6, 0.1, 0]], [[0, 0, -1], [30, 0, -1], [60, 5, -2]]], dtype=float)
+    coeffs, times, seg_rows, offs, traj = host_plan(ctx, wps, 2.0, 0.01)
+    assert seg_rows[0].sum() == offs[1] and offs[2] - offs[1] == seg_rows[1].sum() and seg_rows[0].sum() < 60
+    from oracle import minsnap_oracle as mo
+    for b in range(2):
+        ref = mo.plan(wps[b], 2.0, 0.01, method="solve")
+        assert col_err(traj[offs[b]:offs[b + 1]], ref) < 1e-6
+    # invalid input -> error codes, like the adapter's ValueError (mujoco_sim.py:37-38)
+    bad = wps.copy()
+    bad[1, 1, 0] = np.nan
+    with pytest.raises(nat.UavacError) as e:
+        host_plan(ctx, bad, 2.0, 0.01)
+    assert e.value.code == nat.ENONFINITE
+    with pytest.raises(ValueError):
+        eng.plan(bad, 2.0, 0.01)
+    rep = wps.copy()
+    rep[0, 1] = rep[0, 0]                                   # repeated waypoint: T = 0 -> singular
+    with pytest.raises(nat.UavacError) as e:
+        host_plan(ctx, rep, 2.0, 0.01)
+    assert e.value.code in (nat.ESINGULAR, nat.ENONFINITE)
+    with pytest.raises(nat.UavacError) as e:
+        ctx.call("uavac_minsnap_solve", nat.np_ptr(wps), 2, 0, 2.0, nat.np_ptr(coeffs), None)
+    assert e.value.code == nat.EINVAL
+    # maximum segment count
+    wmax = mo.synthetic_missions(2, nat.MAX_SEGMENTS)
+    plan = eng.plan(wmax, 3.0, 0.01)
+    eng.check(plan)
+    assert col_err(plan.mission(1), mo.plan(wmax[1], 3.0, 0.01, method="solve")) < 1e-6
+
+
+def test_full_size_properties_config2(eng):
+    """BASELINE config 2 size (B = 4096, m = 8): size-independent properties instead of a full oracle run."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    B, m = 4096, 8
+    wps = mo.synthetic_missions(B, m)
+    plan = eng.plan(wps, 3.0, 0.01)
+    eng.check(plan)
+    traj, offs, seg = plan.traj, plan.row_offsets, plan.seg_rows.to(torch.int64)
+    assert plan.total_rows == int(seg.sum()) and bool(torch.isfinite(traj).all())
+    # first row of every segment sits on its waypoint with t = 0 (position = c0 exactly)
+    seg_start = offs[:-1, None] + torch.cumsum(seg, 1) - seg
+    wp_t = torch.as_tensor(wps, device=traj.device)
+    assert bool((traj[seg_start.reshape(-1), 0:3].reshape(B, m, 3) == wp_t[:, :m]).all())
+    # missions start and end at rest (v = a = 0 at t = 0; tiny at the last sample)
+    assert float(traj[offs[:-1], 3:9].abs().max()) == 0.0
+    assert float(traj[offs[1:] - 1, 3:6].abs().max()) < 1e-2
+    # velocity is continuous across every knot (reference test_minimum_snap.py:139-151 bound 0.5)
+    dv = (traj[1:, 3:6] - traj[:-1, 3:6]).norm(dim=1)
+    same = torch.ones(plan.total_rows - 1, dtype=torch.bool, device=traj.device)
+    same[offs[1:-1] - 1] = False
+    assert float(dv[same].max()) < 0.5
+    # spline ids are non-decreasing inside a mission and end at m-1
+    assert bool((traj[offs[1:] - 1, 10] == m - 1).all())
+    # spot-check 4 missions against the oracle
+    for b in (0, 1365, 2730, 4095):
+        assert col_err(plan.mission(b), mo.plan(wps[b], 3.0, 0.01, method="solve")) < 1e-8

@@ -1,0 +1,64 @@
+// Internal declarations shared by the libuavac.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "uavac.h"
+
+struct uavac_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;    // == own_stream unless borrowed
+    int32_t *d_flags = nullptr;      // [4] device-side error flags (0: non-finite input, 1: singular system)
+    int32_t *d_totals = nullptr;     // scratch for the row-count scan
+    size_t totals_cap = 0;
+    std::string err;
+};
+
+#define UAVAC_HIP(ctx, call)                                                                     \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return UAVAC_EHIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+static inline int uavac_fail(uavac_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// Kernel-side view of uavac_vehicle with the per-call constants hoisted on the host.
+struct VehK {
+    double g, dt, dt_outer, mass, inv_mass;
+    double I[3], inv_I[3];
+    double arm, inv_arm, kappa, inv_kappa, kf, inv_kf;
+    double min_thrust, max_thrust, c_min, c_max;
+    double resp_rise, resp_fall;     // 1 - exp(-dt/tau): quad.py:102
+    double max_ascent, max_descent, max_speed_xy, max_horiz_accel, max_tilt;
+    double kp_xy, kd_xy, kp_z, kd_z, ki_z, kp_roll, kp_pitch, kp_yaw;
+    double ikp[3];                   // I * kp_pqr: controller.py:128
+    double hover_omega;
+    int F;
+};
+
+VehK uavac_make_vehk(const uavac_vehicle &V);
+int uavac_check_vehicle(uavac_ctx *ctx, const uavac_vehicle *V);
+
+// launchers (one per .hip file)
+int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
+                            double *times, int32_t *seg_rows, int64_t *row_offsets);
+int uavac_launch_solve(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
+                       int32_t *status);
+int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
+                        int B, int m, double dt, double *traj);
+int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positions, int B, int hover, double *state,
+                            int32_t *istate);
+int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
+                         int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,
+                         int n_obs);

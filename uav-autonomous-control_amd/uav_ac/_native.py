@@ -1,0 +1,140 @@
+"""ctypes binding of libuavac.so (include/uavac.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is usable,
+importing the symbols works (so that `-m "not gpu"` tests can check the ABI) but
+creating a context raises.  Build with `make -C uav-autonomous-control_amd` or
+`python -c "import __graft_entry__ as g; g.build()"`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libuavac.so")
+
+OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM = 0, -1, -2, -3, -4, -5
+MAX_SEGMENTS = 64
+TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 26, 3, 12
+
+
+class UavacError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libuavac error {code}: {msg}")
+        self.code = code
+
+
+class Vehicle(C.Structure):
+    """Mirror of `uavac_vehicle` (include/uavac.h); defaults = lab_course.xml + quad.py:42-73."""
+    _fields_ = [(n, C.c_double) for n in ("g", "dt", "dt_outer", "mass")] + [("inertia", C.c_double * 3)] + \
+               [(n, C.c_double) for n in (
+                   "arm", "kf", "kappa", "min_thrust", "max_thrust", "tau_rise", "tau_fall",
+                   "max_ascent", "max_descent", "max_speed_xy", "max_horiz_accel", "max_tilt",
+                   "kp_xy", "kd_xy", "kp_z", "kd_z", "ki_z", "kp_roll", "kp_pitch", "kp_yaw",
+                   "kp_p", "kp_q", "kp_r")] + [("inner_per_outer", C.c_int32), ("reserved", C.c_int32)]
+
+    @classmethod
+    def default(cls) -> "Vehicle":
+        v = cls()
+        lib().uavac_vehicle_default(C.byref(v))
+        return v
+
+    def copy(self) -> "Vehicle":
+        v = Vehicle()
+        C.memmove(C.byref(v), C.byref(self), C.sizeof(Vehicle))
+        return v
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "uavac_version": (C.c_int, []),
+    "uavac_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "uavac_destroy": (None, [_P]),
+    "uavac_last_error": (C.c_char_p, [_P]),
+    "uavac_set_stream": (C.c_int, [_P, _P]),
+    "uavac_synchronize": (C.c_int, [_P]),
+    "uavac_vehicle_default": (None, [C.POINTER(Vehicle)]),
+    "uavac_minsnap_row_counts_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
+    "uavac_minsnap_solve_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "uavac_minsnap_sample_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P]),
+    "uavac_minsnap_row_counts": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
+    "uavac_minsnap_solve": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
+    "uavac_minsnap_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
+    "uavac_state_init_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
+    "uavac_control_rollout_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
+    "uavac_control_step_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
+    "uavac_state_init": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
+    "uavac_control_rollout": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
+    "uavac_probe_outer": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
+    "uavac_probe_inner": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libuavac.so once.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UavacError(EHIP, f"{LIB_PATH} not built: run `make -C {os.path.dirname(os.path.dirname(LIB_PATH))}`")
+        try:                                   # share torch's HIP runtime when torch is in the process
+            import torch  # noqa: F401
+        except Exception:                      # pragma: no cover - torch is plumbing, not a requirement of the ABI
+            pass
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+class Context:
+    """Owns one `uavac_ctx` (one HIP stream on one GPU)."""
+
+    def __init__(self, device: int = -1):
+        self._h = _P()
+        rc = lib().uavac_create(C.byref(self._h), device)
+        if rc != OK:
+            self._h = _P()
+            raise UavacError(rc, "uavac_create failed: no usable MI355X / HIP runtime (there is no CPU fallback)")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().uavac_destroy(self._h)
+            self._h = _P()
+
+    __del__ = close
+
+    def check(self, rc: int):
+        if rc != OK:
+            msg = lib().uavac_last_error(self._h)
+            raise UavacError(rc, msg.decode() if msg else "")
+
+    def call(self, name: str, *args):
+        self.check(getattr(lib(), name)(self._h, *args))
+
+    def set_stream(self, stream_handle):
+        self.call("uavac_set_stream", _P(stream_handle or None))
+
+    def synchronize(self):
+        self.call("uavac_synchronize")
+
+
+def np_ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def as_f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a

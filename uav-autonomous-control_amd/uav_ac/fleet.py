@@ -1,0 +1,238 @@
+"""Batched host API over libuavac.so: plan B missions, fly B UAVs.
+
+This is the batched form of the reference's single-UAV flow in uav_ac/main.py:87-120
+(`MinimumSnap(...).get_trajectory()` once per mission, then `TrajectoryController.step()` +
+`simulation.step()` per tick).  PyTorch is plumbing only: it owns device memory and the HIP
+stream, and `torch.distributed` carries the final gather; all arithmetic happens in the
+hand-written HIP kernels behind the C ABI (include/uavac.h).  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _native as nat
+
+_P = C.c_void_p
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t) -> _P:
+    return _P(0 if t is None else t.data_ptr())
+
+
+@dataclass
+class Plan:
+    """Device-resident result of planning B missions of m segments."""
+    B: int
+    m: int
+    velocity: float
+    dt: float
+    waypoints: "object"      # (B, m+1, 3) f64
+    times: "object"          # (B, m) f64
+    seg_rows: "object"       # (B, m) i32
+    row_offsets: "object"    # (B+1,) i64
+    coeffs: "object"         # (B, 8m, 3) f64
+    status: "object"         # (B,) i32: 0 ok, 1 singular
+    traj: "object"           # (N, 11) f64, missions back to back
+    total_rows: int
+
+    def mission(self, b: int) -> np.ndarray:
+        """Rows of mission b as a fresh host array (N_b, 11) -- the reference's `full_trajectory`."""
+        ro = self.row_offsets[b:b + 2].cpu().numpy()
+        return self.traj[int(ro[0]):int(ro[1])].cpu().numpy().copy()
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        """24(m+1) in + 192 m coefficients out + 88 N rows out, per mission, summed."""
+        return self.B * (24 * (self.m + 1) + 192 * self.m) + 88 * self.total_rows
+
+
+class Engine:
+    """One GPU, one `uavac_ctx`.  Kernels are enqueued on torch's current stream for that device."""
+
+    def __init__(self, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise nat.UavacError(nat.EHIP, "no GPU visible: the uavac engine has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            self.ctx = nat.Context(self.device.index)
+        self._torch = torch
+
+    # -- plumbing ---------------------------------------------------------------
+    def _bind_stream(self):
+        self.ctx.set_stream(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype):
+        torch = self._torch
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    # -- planning ---------------------------------------------------------------
+    def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01) -> Plan:
+        """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124)."""
+        torch = self._torch
+        wp = self._dev(waypoints, torch.float64)
+        if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
+            raise ValueError(f"waypoints must have shape (B, m+1, 3), got {tuple(wp.shape)}")
+        if not bool(torch.isfinite(wp).all()):
+            raise ValueError("waypoints must be finite")
+        B, m = int(wp.shape[0]), int(wp.shape[1]) - 1
+        kw = dict(device=self.device)
+        times = torch.empty((B, m), dtype=torch.float64, **kw)
+        seg_rows = torch.empty((B, m), dtype=torch.int32, **kw)
+        row_offsets = torch.empty((B + 1,), dtype=torch.int64, **kw)
+        coeffs = torch.empty((B, 8 * m, 3), dtype=torch.float64, **kw)
+        status = torch.zeros((B,), dtype=torch.int32, **kw)
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_row_counts_dev", _ptr(wp), B, m, float(velocity), float(dt), _ptr(times),
+                      _ptr(seg_rows), _ptr(row_offsets))
+        self.ctx.call("uavac_minsnap_solve_dev", _ptr(wp), _ptr(times), B, m, _ptr(coeffs), _ptr(status))
+        total = int(row_offsets[-1].item())                 # the one host sync: sizes the trajectory buffer
+        traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
+        plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total)
+        self.sample(plan)
+        return plan
+
+    def solve(self, plan: Plan):
+        """Re-run times/row counts + coefficient solve into plan's buffers (no allocation, no sync)."""
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_row_counts_dev", _ptr(plan.waypoints), plan.B, plan.m, plan.velocity, plan.dt,
+                      _ptr(plan.times), _ptr(plan.seg_rows), _ptr(plan.row_offsets))
+        self.ctx.call("uavac_minsnap_solve_dev", _ptr(plan.waypoints), _ptr(plan.times), plan.B, plan.m,
+                      _ptr(plan.coeffs), _ptr(plan.status))
+
+    def sample(self, plan: Plan):
+        """Re-run the sampler + yaw scan into plan.traj (no allocation, no sync)."""
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_sample_dev", _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows),
+                      _ptr(plan.row_offsets), plan.B, plan.m, plan.dt, _ptr(plan.traj))
+
+    def check(self, plan: Plan):
+        """Raise like the C ABI's host twins would: singular knot systems (repeated waypoints)."""
+        if bool((plan.status != 0).any()):
+            bad = int((plan.status != 0).nonzero()[0])
+            raise nat.UavacError(nat.ESINGULAR, f"mission {bad}: singular knot system (repeated waypoint?)")
+
+    # -- control ----------------------------------------------------------------
+    def fleet(self, plan: Plan, vehicle: Optional[nat.Vehicle] = None, hover: bool = True,
+              positions=None) -> "Fleet":
+        return Fleet(self, plan, vehicle, hover, positions)
+
+
+class Fleet:
+    """B UAVs tracking the B missions of a Plan: batched TrajectoryController + free-flight simulation."""
+
+    def __init__(self, engine: Engine, plan: Plan, vehicle=None, hover=True, positions=None):
+        torch = engine._torch
+        self.engine, self.plan = engine, plan
+        self.vehicle = vehicle if vehicle is not None else nat.Vehicle.default()
+        self.B = plan.B
+        self.state = torch.empty((nat.STATE_ROWS, self.B), dtype=torch.float64, device=engine.device)
+        self.istate = torch.empty((nat.ISTATE_ROWS, self.B), dtype=torch.int32, device=engine.device)
+        self._hover = bool(hover)
+        self._positions = (engine._dev(positions, torch.float64) if positions is not None
+                           else plan.waypoints[:, 0, :].contiguous())
+        self.reset()
+
+    def reset(self):
+        """`TrajectoryController.reset` (main.py:29-35) + vehicle back at its first waypoint, at rest."""
+        e = self.engine
+        e._bind_stream()
+        e.ctx.call("uavac_state_init_dev", C.byref(self.vehicle), _ptr(self._positions), self.B,
+                   int(self._hover), _ptr(self.state), _ptr(self.istate))
+
+    def rollout(self, K: int, state_log=None, cmd_log=None, aabbs=None):
+        """K fused ticks.  state_log / cmd_log: None, True (allocate) or a preallocated tensor.
+
+        Returns (state_log (K,13,B) | None, cmd_log (K,12,B) | None).
+        """
+        e, torch = self.engine, self.engine._torch
+        if state_log is True:
+            state_log = torch.empty((K, 13, self.B), dtype=torch.float64, device=e.device)
+        if cmd_log is True:
+            cmd_log = torch.empty((K, nat.CMD_COLS, self.B), dtype=torch.float64, device=e.device)
+        for name, t, rows in (("state_log", state_log, 13), ("cmd_log", cmd_log, nat.CMD_COLS)):
+            if t is not None and (t.dtype != torch.float64 or not t.is_contiguous() or t.numel() < K * rows * self.B):
+                raise ValueError(f"{name} must be a contiguous float64 tensor with >= K*{rows}*B elements")
+        ab, n_obs = None, 0
+        if aabbs is not None:
+            ab = e._dev(aabbs, torch.float64).reshape(-1, 6)
+            n_obs = int(ab.shape[0])
+        e._bind_stream()
+        e.ctx.call("uavac_control_rollout_dev", C.byref(self.vehicle), _ptr(self.plan.traj),
+                   _ptr(self.plan.row_offsets), _ptr(self.state), _ptr(self.istate), self.B, int(K),
+                   _ptr(state_log), _ptr(cmd_log), _ptr(ab), n_obs)
+        return state_log, cmd_log
+
+    def step(self):
+        """One tick: `tc.step()` + `simulation.step()` for every UAV (main.py:37-45, mujoco_sim.py:144-151)."""
+        e = self.engine
+        e._bind_stream()
+        e.ctx.call("uavac_control_step_dev", C.byref(self.vehicle), _ptr(self.plan.traj),
+                   _ptr(self.plan.row_offsets), _ptr(self.state), _ptr(self.istate), self.B)
+
+    # views -------------------------------------------------------------------------
+    @property
+    def X(self):
+        return self.state[0:13]
+
+    @property
+    def trajectory_index(self):
+        return self.istate[0]
+
+    @property
+    def collided(self):
+        return self.istate[2]
+
+    @staticmethod
+    def algorithmic_bytes(B: int, K: int, F: int = 10) -> float:
+        """104 B state log per UAV tick + one 88 B trajectory row per outer tick."""
+        return float(B) * K * (104.0 + 88.0 / F)
+
+
+# ---------------------------------------------------------------------- multi-GPU
+def shard_bounds(B: int, rank: int, world: int):
+    """Contiguous mission-index block of this rank: no data-path collective needed."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_rows(rows, dst: int = 0, group=None):
+    """Gather ragged (n_r, C) row blocks to `dst` with point-to-point sends (one direct xGMI link per
+    peer into the root; a ring all-gather would push 7/8 of the total through every link).
+
+    Works on CPU tensors with gloo and on GPU tensors with nccl (= RCCL).  Returns (all_rows,
+    counts) on dst and (None, counts) elsewhere.
+    """
+    torch = _torch()
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    if world == 1:
+        return rows, counts
+    if rank == dst:
+        out = torch.empty((sum(counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        out[offs[dst]:offs[dst + 1]].copy_(rows)
+        reqs = [dist.irecv(out[offs[r]:offs[r + 1]], src=dist.get_global_rank(group, r) if group else r, group=group)
+                for r in range(world) if r != dst and counts[r] > 0]
+        for q in reqs:
+            q.wait()
+        return out, counts
+    if counts[rank] > 0:
+        dist.isend(rows.contiguous(), dst=dist.get_global_rank(group, dst) if group else dst, group=group).wait()
+    return None, counts
