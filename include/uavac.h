@@ -73,9 +73,11 @@ int uavac_version(void);
 int uavac_create(uavac_ctx **out, int device_id);
 void uavac_destroy(uavac_ctx *ctx);
 const char *uavac_last_error(const uavac_ctx *ctx);
-/* Borrow a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the ctx-owned stream. */
+/* Borrow a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL is a
+ * valid handle: HIP's legacy default stream (what torch uses unless told otherwise).
+ * uavac_reset_stream goes back to the ctx-owned (non-blocking) stream. */
 int uavac_set_stream(uavac_ctx *ctx, void *hip_stream);
+int uavac_reset_stream(uavac_ctx *ctx);
 int uavac_synchronize(uavac_ctx *ctx);
 /* Fill *V with the laboratory vehicle (lab_course.xml) and the gains of quad.py:42-73. */
 void uavac_vehicle_default(uavac_vehicle *V);
@@ -148,6 +150,21 @@ int uavac_state_init(uavac_ctx *ctx, const uavac_vehicle *V, const double *posit
 int uavac_control_rollout(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
                           const int64_t *row_offsets, double *state, int32_t *istate, int B, int K,
                           double *state_log, double *cmd_log, const double *aabbs, int n_obs);
+
+/* The two halves of a tick on their own, for callers that own the simulation loop the way
+ * uav_ac/main.py does (controller callback + external physics):
+ *   uavac_controller_tick = TrajectoryController.step (main.py:37-61): outer loop every
+ *       inner_per_outer-th call, body-rate loop, allocation, motor lag; X is read, not advanced;
+ *   uavac_dynamics_step   = MujocoSimulation.step in free flight (mujoco_sim.py:144-151,232-251):
+ *       advances X from the current rotor speeds; aabbs/istate optional (sticky flag in istate row 2). */
+int uavac_controller_tick_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
+                              const int64_t *row_offsets, double *state, int32_t *istate, int B);
+int uavac_dynamics_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate,
+                            int B, const double *aabbs, int n_obs);
+int uavac_controller_tick(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
+                          const int64_t *row_offsets, double *state, int32_t *istate, int B);
+int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate, int B,
+                        const double *aabbs, int n_obs);
 
 /* ---- per-function probes ------------------------------------------------------
  * One stage of the control law at a time on small array-of-struct batches (host pointers,

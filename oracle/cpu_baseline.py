@@ -1,0 +1,41 @@
+"""CPU baseline leg of bench.py: the C oracle (a scalar port of the reference's per-UAV algorithm,
+oracle/uavac_oracle.c) timed on the host, one thread, on a bounded sample of the bench workload.
+TEST INFRASTRUCTURE -- measured next to the GPU number, never part of it."""
+from __future__ import annotations
+
+import time
+
+from . import c_oracle as co
+from .minsnap_oracle import synthetic_missions
+
+
+def run(segments: int, ticks: int, velocity: float, dt: float, budget_s: float = 12.0, max_missions: int = 100000):
+    wps = synthetic_missions(min(max_missions, 4096), segments)     # recycled if the budget outlasts them
+    V = co.Vehicle.default()
+    co.plan(wps[0], velocity, dt)                       # warm-up (page in, build if needed)
+    n = 0
+    t_plan = t_roll = 0.0
+    rows = 0
+    t_start = time.perf_counter()
+    while n < max_missions and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        traj, _, _ = co.plan(wps[n % len(wps)], velocity, dt)
+        t1 = time.perf_counter()
+        state, istate = co.initial_state(traj[0, 0:3], V)
+        co.rollout(traj, state, istate, ticks, V, log_state=True, log_cmd=False)
+        t2 = time.perf_counter()
+        t_plan += t1 - t0
+        t_roll += t2 - t1
+        rows += len(traj)
+        n += 1
+    total = t_plan + t_roll
+    return {
+        "value": n * ticks / total,
+        "unit": "UAV control-steps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n} missions of the same generator: plan ({segments} segments, {rows} rows) + {ticks} ticks each, "
+                  f"scalar C oracle (gcc -O2), {total:.1f} s of CPU",
+        "control_only_steps_per_s": n * ticks / t_roll,
+        "minsnap_segments_per_s": n * segments / t_plan,
+    }

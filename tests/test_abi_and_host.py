@@ -1,0 +1,82 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/uavac.h declares, the
+ctypes mirror of uavac_vehicle matches the header, the engine refuses to run without a GPU (no CPU
+fallback), and the product package never imports the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import PKG, REPO
+
+
+def header_functions():
+    text = open(os.path.join(REPO, "include", "uavac.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(uavac_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from uav_ac import _native as nat
+    lib = nat.lib()
+    declared = header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/uavac.h but not exported"
+    assert sorted(nat.exported_symbols()) == declared       # the ctypes table covers the header exactly
+    assert lib.uavac_version() == 100
+
+
+def test_vehicle_struct_layout_and_defaults():
+    from uav_ac import _native as nat
+    text = open(os.path.join(REPO, "include", "uavac.h")).read()
+    body = text[text.index("typedef struct uavac_vehicle {"):text.index("} uavac_vehicle;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    n_doubles = 0
+    for decl in re.findall(r"double\s+([^;]+);", body):
+        for item in decl.split(","):
+            mm = re.search(r"\[(\d+)\]", item)
+            n_doubles += int(mm.group(1)) if mm else 1
+    assert C.sizeof(nat.Vehicle) == 8 * n_doubles + 8
+    V = nat.Vehicle.default()                              # pure host function: works without a GPU
+    assert (V.g, V.dt, V.mass, V.kappa, V.inner_per_outer) == (9.81, 0.001, 0.5, 0.016, 10)
+    assert list(V.inertia) == [0.0023, 0.0023, 0.0046]
+    assert V.kp_z == 1 / 0.2 ** 2 and V.kp_r == 1 / 0.09     # quad.py:53-73
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from uav_ac import _native as nat
+    from uav_ac.fleet import Engine
+    with pytest.raises(nat.UavacError):
+        nat.Context(0)
+    with pytest.raises(nat.UavacError):
+        Engine()
+    from uav_ac.planning.minimum_snap import MinimumSnap
+    with pytest.raises(nat.UavacError):
+        MinimumSnap(np.array([[0., 0, 0], [1, 0, 0]]), None, 1.0, 0.01).get_trajectory()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")) or f == "Makefile":
+                src = open(os.path.join(root, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src or "oracle/" in src:
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad
+
+
+def test_shard_bounds_partition_the_batch():
+    from uav_ac.fleet import shard_bounds
+    for B in (1, 7, 65536, 262144):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -308,28 +308,45 @@ def test_collision_flag_config5(eng):
 
 
 def test_full_size_rollout_properties_config2(eng):
-    """BASELINE config 2 size (B = 4096, m = 8): tracking stays bounded, state finite, quaternion unit,
-    every UAV reaches the end of its mission; 3 lanes spot-checked against the oracle over 2000 ticks."""
+    """BASELINE config 2 size (B = 4096, m = 8, 10 000 ticks).  The reference controller does not hold every
+    SURVEY.md 8(d) mission (3 m legs with random turns at 3 m/s ask for > 9 m/s^2): the C oracle loses
+    about one in seven.  So the size-independent properties are: the SAME lanes are lost on the GPU as in
+    the oracle, kept lanes end within the reference's 0.5 m acceptance and agree with the oracle to 1e-5,
+    every trajectory cursor reaches its last row, kept lanes stay finite with unit quaternions."""
     import torch
-    from oracle import control_oracle as co
+    from oracle import c_oracle as cc
     from oracle import minsnap_oracle as mo
-    B, m = 4096, 8
+    B, m, K = 4096, 8, 10000
     wps = mo.synthetic_missions(B, m)
     plan = eng.plan(wps, 3.0, 0.01)
     fleet = eng.fleet(plan)
     slog, _ = fleet.rollout(2000, state_log=True)
-    for b in (0, 2047, 4095):
-        traj = plan.mission(b)
-        u = co.UAV(co.Vehicle(), position=traj[0, 0:3])
-        s_ref, _ = co.rollout(u, traj, 2000)
-        assert col_err(slog[:, :, b].cpu().numpy(), s_ref) < TOL
+    lanes = list(range(0, 64)) + [2047, 4095]
+    head = {b: slog[:, :, b].cpu().numpy() for b in (0, 2047, 4095)}
     del slog
-    fleet.rollout(8000)
+    fleet.rollout(K - 2000)
     torch.cuda.synchronize()
-    X = fleet.X
-    assert bool(torch.isfinite(fleet.state).all())
-    assert float((X[3:7].norm(dim=0) - 1).abs().max()) < 1e-12
-    nrows = plan.row_offsets[1:] - plan.row_offsets[:-1]
-    assert bool((fleet.trajectory_index.to(torch.int64) == nrows - 1).all())
-    goal = torch.as_tensor(wps[:, -1, :].T.copy(), device=X.device)
-    assert float((X[0:3] - goal).norm(dim=0).max()) < 0.5            # reference acceptance: < 0.5 m from goal
+    X = fleet.X.cpu().numpy()
+    goal = wps[:, -1, :].T
+    miss = np.linalg.norm(X[0:3] - goal, axis=0)
+    lost_gpu, lost_cpu = [], []
+    for b in lanes:
+        traj = plan.mission(b)
+        state, istate = cc.initial_state(traj[0, 0:3])
+        s_ref, _ = cc.rollout(traj, state, istate, K, log_cmd=False)
+        ref_miss = np.linalg.norm(state[0:3] - wps[b, -1])
+        if b in head:
+            assert col_err(head[b], s_ref[:2000]) < TOL
+        if ref_miss > 0.5:
+            lost_cpu.append(b)
+        else:
+            assert col_err(X[:, b][None], state[None, 0:13]) < TOL
+        if miss[b] > 0.5:
+            lost_gpu.append(b)
+    assert lost_gpu == lost_cpu and 0 < len(lost_cpu) < len(lanes) // 2
+    kept = miss < 0.5
+    assert 0.75 < kept.mean() < 0.95
+    assert np.isfinite(X[:, kept]).all()
+    assert np.abs(np.linalg.norm(X[3:7, kept], axis=0) - 1).max() < 1e-12
+    nrows = (plan.row_offsets[1:] - plan.row_offsets[:-1]).cpu().numpy()
+    assert np.array_equal(fleet.trajectory_index.cpu().numpy(), nrows - 1)

@@ -72,6 +72,67 @@ __global__ void probe_inner_kernel(const VehK V, const double *__restrict__ in, 
     for (int i = 0; i < 4; ++i) { o[3 + i] = f[i]; o[7 + i] = omc[i]; o[11 + i] = om[i]; }
 }
 
+
+// Controller half of a tick on SoA state (TrajectoryController.step, main.py:37-61): outer loop every
+// F-th call, body-rate loop, allocation and motor lag.  Does NOT integrate the vehicle.
+__global__ void controller_tick_kernel(const VehK V, const double *__restrict__ traj,
+                                       const int64_t *__restrict__ row_offsets, double *__restrict__ state,
+                                       int32_t *__restrict__ istate, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t sB = (size_t)B;
+    double X[13], om[4], omc[4];
+    for (int i = 0; i < 13; ++i) X[i] = state[i * sB + b];
+    for (int i = 0; i < 4; ++i) { om[i] = state[(13 + i) * sB + b]; omc[i] = state[(17 + i) * sB + b]; }
+    double integ = state[21 * sB + b], thrust = state[22 * sB + b];
+    double pc = state[23 * sB + b], qc = state[24 * sB + b], rc = state[25 * sB + b];
+    int idx = istate[b], inner = istate[sB + b];
+    const int64_t off = row_offsets[b];
+    const int nrows = (int)(row_offsets[b + 1] - off);
+    if (inner % V.F == 0 && nrows > 0) {
+        const double *tg = traj + (off + min(max(idx, 0), nrows - 1)) * UAVAC_TRAJ_COLS;
+        const Rot R = quat_to_rot(X[3], X[4], X[5], X[6]);
+        thrust = altitude(V, tg[2], tg[5], tg[8], X[2], X[9], R.r22, integ);
+        double bxc, byc;
+        lateral(V, tg[0], tg[3], tg[6], tg[1], tg[4], tg[7], X[0], X[1], X[7], X[8], thrust, bxc, byc);
+        roll_pitch(V, bxc, byc, R, pc, qc);
+        double psi, cth, sphi, cphi;
+        euler_trig(X[3], X[4], X[5], X[6], psi, cth, sphi, cphi);
+        rc = yaw_rate(V, tg[9], psi, cth, sphi, cphi, qc);
+        idx = min(idx + 1, nrows - 1);
+    }
+    double Mx, My, Mz, f[4];
+    body_rate(V, pc, qc, rc, X[10], X[11], X[12], Mx, My, Mz);
+    allocate(V, thrust, Mx, My, Mz, f);
+    motors(V, f, om, omc);
+    for (int i = 0; i < 4; ++i) { state[(13 + i) * sB + b] = om[i]; state[(17 + i) * sB + b] = omc[i]; }
+    state[21 * sB + b] = integ; state[22 * sB + b] = thrust;
+    state[23 * sB + b] = pc; state[24 * sB + b] = qc; state[25 * sB + b] = rc;
+    istate[b] = idx; istate[sB + b] = inner + 1;
+}
+
+// Vehicle half of a tick (MujocoSimulation.step in free flight, mujoco_sim.py:144-151): rotor wrench +
+// semi-implicit Euler free-body step on X from the current rotor speeds, optional sticky AABB flag.
+__global__ void dynamics_step_kernel(const VehK V, double *__restrict__ state, int32_t *__restrict__ istate, int B,
+                                     const double *__restrict__ aabbs, int n_obs) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t sB = (size_t)B;
+    double X[13], om[4];
+    for (int i = 0; i < 13; ++i) X[i] = state[i * sB + b];
+    for (int i = 0; i < 4; ++i) om[i] = state[(13 + i) * sB + b];
+    free_body_step(V, om, X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11], X[12]);
+    for (int i = 0; i < 13; ++i) state[i * sB + b] = X[i];
+    if (aabbs && istate) {
+        int hit = 0;
+        for (int o = 0; o < n_obs; ++o) {
+            const double *c = aabbs + 6 * o;
+            hit |= (X[0] >= c[0] && X[0] <= c[1] && X[1] >= c[2] && X[1] <= c[3] && X[2] >= c[4] && X[2] <= c[5]);
+        }
+        if (hit) istate[2 * sB + b] = 1;
+    }
+}
+
 struct Scratch {
     void *p = nullptr;
     ~Scratch() { if (p) (void)hipFree(p); }
@@ -105,6 +166,73 @@ int uavac_probe_outer(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, 
 
 int uavac_probe_inner(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out) {
     return run_probe(ctx, V, probe_inner_kernel, in, UAVAC_PROBE_INNER_IN, B, mask, out, UAVAC_PROBE_INNER_OUT);
+}
+
+int uavac_controller_tick_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,
+                              double *state, int32_t *istate, int B) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (int rc = uavac_check_vehicle(ctx, V)) return rc;
+    if (B < 1 || !traj || !row_offsets || !state || !istate) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    hipLaunchKernelGGL(controller_tick_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, uavac_make_vehk(*V), traj,
+                       row_offsets, state, istate, B);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
+int uavac_dynamics_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate, int B,
+                            const double *aabbs, int n_obs) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (int rc = uavac_check_vehicle(ctx, V)) return rc;
+    if (B < 1 || !state || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    hipLaunchKernelGGL(dynamics_step_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, uavac_make_vehk(*V), state,
+                       istate, B, n_obs > 0 ? aabbs : nullptr, n_obs);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
+int uavac_controller_tick(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,
+                          double *state, int32_t *istate, int B) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (B < 1 || !traj || !row_offsets || !state || !istate) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    if (row_offsets[0] != 0) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must start at 0");
+    const size_t total = (size_t)row_offsets[B];
+    Scratch dtr, dro, ds, di;
+    UAVAC_HIP(ctx, hipMalloc(&dtr.p, total * UAVAC_TRAJ_COLS * 8 + 8));
+    UAVAC_HIP(ctx, hipMalloc(&dro.p, ((size_t)B + 1) * 8));
+    UAVAC_HIP(ctx, hipMalloc(&ds.p, (size_t)B * UAVAC_STATE_ROWS * 8));
+    UAVAC_HIP(ctx, hipMalloc(&di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4));
+    UAVAC_HIP(ctx, hipMemcpyAsync(dtr.p, traj, total * UAVAC_TRAJ_COLS * 8, hipMemcpyHostToDevice, ctx->stream));
+    UAVAC_HIP(ctx, hipMemcpyAsync(dro.p, row_offsets, ((size_t)B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    UAVAC_HIP(ctx, hipMemcpyAsync(ds.p, state, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyHostToDevice, ctx->stream));
+    UAVAC_HIP(ctx, hipMemcpyAsync(di.p, istate, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = uavac_controller_tick_dev(ctx, V, static_cast<double *>(dtr.p), static_cast<int64_t *>(dro.p),
+                                           static_cast<double *>(ds.p), static_cast<int32_t *>(di.p), B)) return rc;
+    UAVAC_HIP(ctx, hipMemcpyAsync(state, ds.p, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    UAVAC_HIP(ctx, hipMemcpyAsync(istate, di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UAVAC_OK;
+}
+
+int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate, int B,
+                        const double *aabbs, int n_obs) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (B < 1 || !state || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    Scratch ds, di, dab;
+    UAVAC_HIP(ctx, hipMalloc(&ds.p, (size_t)B * UAVAC_STATE_ROWS * 8));
+    UAVAC_HIP(ctx, hipMemcpyAsync(ds.p, state, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyHostToDevice, ctx->stream));
+    const bool flag = istate && aabbs && n_obs > 0;
+    if (flag) {
+        UAVAC_HIP(ctx, hipMalloc(&di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4));
+        UAVAC_HIP(ctx, hipMalloc(&dab.p, (size_t)n_obs * 48));
+        UAVAC_HIP(ctx, hipMemcpyAsync(di.p, istate, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyHostToDevice, ctx->stream));
+        UAVAC_HIP(ctx, hipMemcpyAsync(dab.p, aabbs, (size_t)n_obs * 48, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (int rc = uavac_dynamics_step_dev(ctx, V, static_cast<double *>(ds.p), flag ? static_cast<int32_t *>(di.p) : nullptr,
+                                         B, flag ? static_cast<double *>(dab.p) : nullptr, flag ? n_obs : 0)) return rc;
+    UAVAC_HIP(ctx, hipMemcpyAsync(state, ds.p, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (flag) UAVAC_HIP(ctx, hipMemcpyAsync(istate, di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UAVAC_OK;
 }
 
 }  // extern "C"

@@ -101,7 +101,7 @@ int uavac_create(uavac_ctx **out, int device_id) {
 
 void uavac_destroy(uavac_ctx *ctx) {
     if (!ctx) return;
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_totals) (void)hipFree(ctx->d_totals);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -112,7 +112,13 @@ const char *uavac_last_error(const uavac_ctx *ctx) { return ctx ? ctx->err.c_str
 
 int uavac_set_stream(uavac_ctx *ctx, void *hip_stream) {
     if (!ctx) return UAVAC_EINVAL;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);      // NULL = HIP's legacy default stream
+    return UAVAC_OK;
+}
+
+int uavac_reset_stream(uavac_ctx *ctx) {
+    if (!ctx) return UAVAC_EINVAL;
+    ctx->stream = ctx->own_stream;
     return UAVAC_OK;
 }
 

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "uavac_destroy": (None, [_P]),
     "uavac_last_error": (C.c_char_p, [_P]),
     "uavac_set_stream": (C.c_int, [_P, _P]),
+    "uavac_reset_stream": (C.c_int, [_P]),
     "uavac_synchronize": (C.c_int, [_P]),
     "uavac_vehicle_default": (None, [C.POINTER(Vehicle)]),
     "uavac_minsnap_row_counts_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
@@ -68,6 +69,10 @@ _SIGNATURES = {
     "uavac_control_step_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
     "uavac_state_init": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
     "uavac_control_rollout": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
+    "uavac_controller_tick_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
+    "uavac_dynamics_step_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, C.c_int, _P, C.c_int]),
+    "uavac_controller_tick": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
+    "uavac_dynamics_step": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, C.c_int, _P, C.c_int]),
     "uavac_probe_outer": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
     "uavac_probe_inner": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
 }
@@ -123,7 +128,11 @@ class Context:
         self.check(getattr(lib(), name)(self._h, *args))
 
     def set_stream(self, stream_handle):
+        """Borrow a hipStream_t handle; 0 / None is HIP's legacy default stream (torch's default)."""
         self.call("uavac_set_stream", _P(stream_handle or None))
+
+    def reset_stream(self):
+        self.call("uavac_reset_stream")
 
     def synchronize(self):
         self.call("uavac_synchronize")
