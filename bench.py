@@ -132,16 +132,18 @@ def main():
     roll_avg_s = float(np.mean(roll_ms)) * 1e-3
     plan_avg_s = float(np.mean(plan_ms)) * 1e-3
 
-    # sanity inside the bench: share of UAVs that end within the reference's 0.5 m acceptance.  The
-    # reference controller itself loses about 1 in 7 of the 8(d) missions (the CPU oracle loses the same
-    # lanes, tests/test_gpu_control.py); the work per tick is identical either way.
-    X = fleet.X
-    goal = plan.waypoints[:, -1, :].T
-    miss = (X[0:3] - goal).norm(dim=0)
-    kept = miss < 0.5
+    # sanity inside the bench: after TICKS ticks every cursor must sit at min(TICKS/F, rows-1) exactly, and
+    # the share of UAVs within the reference's 0.5 m acceptance of their current target row is reported.
+    # (The reference controller itself loses about 1 in 7 of the 8(d) missions -- the CPU oracle loses the
+    # same lanes, tests/test_gpu_control.py -- the work per tick is identical either way.)
+    nrows = plan.row_offsets[1:] - plan.row_offsets[:-1]
+    idx = fleet.trajectory_index.long()
+    cursor_ok = bool((idx == torch.clamp(torch.full_like(nrows, TICKS // F), max=nrows - 1)).all())
+    target = plan.traj[plan.row_offsets[:-1] + idx, 0:3].T
+    track = (fleet.X[0:3] - target).norm(dim=0)
+    kept = track < 0.5
     frac_kept = float(kept.double().mean())
     finite_kept = bool(torch.isfinite(fleet.state[:, kept]).all())
-    cursor_done = bool((fleet.trajectory_index.long() == plan.row_offsets[1:] - plan.row_offsets[:-1] - 1).all())
 
     # final gather of the sampled trajectories to rank 0 (north_star: the only collective)
     gather_ms = None
@@ -194,8 +196,8 @@ def main():
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
                                  "algorithmic_bytes": plan.algorithmic_bytes}},
-        "checks": {"frac_uavs_within_0.5m_of_goal": frac_kept, "kept_lanes_finite": finite_kept,
-                   "all_trajectory_cursors_at_last_row": cursor_done},
+        "checks": {"frac_uavs_within_0.5m_of_target_row": frac_kept, "tracking_lanes_finite": finite_kept,
+                   "all_trajectory_cursors_exact": cursor_ok},
     }
     if gather_ms is not None:
         out["gather_ms"] = gather_ms

@@ -1,0 +1,98 @@
+"""Single-UAV facade with the surface of the reference's `uav_ac/main.py`: `TrajectoryController`
+(one inner body-rate cycle per `step()`, outer loop every `inner_loop_frequency` steps) and the
+mission-assembly helpers.  `step()` is one call of `uavac_controller_tick` (B = 1); the vehicle
+state is whatever the caller's simulation wrote into `quad.X`, as in the reference.  A free-flight
+stand-in for `MujocoSimulation.step()` is `FreeFlightSimulation` below.  Fleet-scale: `uav_ac.fleet`."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from ._single import ctx, vehicle_from
+from .control.controller import CascadedController
+from .planning.minimum_snap import MinimumSnap
+from .quadrotor.quad import Quad
+
+
+class TrajectoryController:
+    def __init__(self, controller: CascadedController, quad: Quad, trajectory: np.ndarray, inner_loop_frequency: int):
+        self.controller = controller
+        self.quad = quad
+        self.trajectory = trajectory
+        self.inner_loop_frequency = inner_loop_frequency
+        self.trajectory_index = 0
+        self.inner_step = 0
+        self.thrust_cmd = 0.0
+        self.pqr_cmd = np.zeros(3)
+
+    def reset(self) -> None:
+        self.controller.reset()
+        self.trajectory_index = 0
+        self.inner_step = 0
+        self.thrust_cmd = 0.0
+        self.pqr_cmd.fill(0.0)
+
+    def step(self) -> None:
+        """One `tc.step()` of the reference (main.py:37-61) on the GPU."""
+        q = self.quad
+        V = vehicle_from(q, g=self.controller.g, dt_outer=self.controller.dt)
+        V.inner_per_outer = int(self.inner_loop_frequency)
+        traj = nat.as_f64(self.trajectory)
+        state = np.zeros((nat.STATE_ROWS, 1))
+        state[0:13, 0] = q.X
+        state[13:17, 0] = q.omega
+        state[17:21, 0] = q.omega_command
+        state[21, 0] = self.controller.integral_error
+        state[22, 0] = self.thrust_cmd
+        state[23:26, 0] = self.pqr_cmd
+        istate = np.array([[self.trajectory_index], [self.inner_step], [0]], dtype=np.int32)
+        offs = np.array([0, len(traj)], dtype=np.int64)
+        ctx().call("uavac_controller_tick", C.byref(V), nat.np_ptr(traj), nat.np_ptr(offs), nat.np_ptr(state),
+                   nat.np_ptr(istate), 1)
+        q.omega = state[13:17, 0].copy()
+        q.omega_command = state[17:21, 0].copy()
+        self.controller.integral_error = state[21, 0]
+        self.thrust_cmd = state[22, 0]
+        self.pqr_cmd = state[23:26, 0].copy()
+        self.trajectory_index = int(istate[0, 0])
+        self.inner_step = int(istate[1, 0])
+
+
+class FreeFlightSimulation:
+    """Free-flight subset of the reference's `MujocoSimulation` (mujoco_sim.py:144-151,232-251): `step()`
+    applies the rotor wrench and advances `quad.X` by one semi-implicit Euler step on the GPU.  No contacts,
+    no scene, no viewer."""
+
+    def __init__(self, quad: Quad, obstacles=None):
+        self.quad = quad
+        self.obstacles = None if obstacles is None else nat.as_f64(obstacles).reshape(-1, 6)
+        self.collision_detected = False
+
+    def step(self) -> np.ndarray:
+        q = self.quad
+        V = vehicle_from(q)
+        state = np.zeros((nat.STATE_ROWS, 1))
+        state[0:13, 0] = q.X
+        state[13:17, 0] = q.omega
+        istate = np.zeros((3, 1), dtype=np.int32)
+        n_obs = 0 if self.obstacles is None else len(self.obstacles)
+        ctx().call("uavac_dynamics_step", C.byref(V), nat.np_ptr(state), nat.np_ptr(istate), 1,
+                   nat.np_ptr(self.obstacles), n_obs)
+        q.X = state[0:13, 0].copy()
+        self.collision_detected = self.collision_detected or bool(istate[2, 0])
+        return q.X.copy()
+
+
+def _trajectory_after_takeoff(trajectory: np.ndarray, takeoff_waypoint: np.ndarray) -> np.ndarray:
+    """Trajectory from the sample nearest the takeoff waypoint (reference main.py:64-70)."""
+    d = np.linalg.norm(trajectory[:, :3] - takeoff_waypoint, axis=1)
+    return trajectory[np.argmin(d):]
+
+
+def _generate_mission_trajectory(waypoints: np.ndarray, obstacles, velocity: float, dt: float) -> np.ndarray:
+    """Isolated vertical takeoff spline followed by the course (reference main.py:73-84)."""
+    takeoff = MinimumSnap(waypoints[:2], obstacles, velocity, dt).get_trajectory()
+    course = MinimumSnap(waypoints[1:], obstacles, velocity, dt).get_trajectory()
+    return np.vstack((takeoff, course))
