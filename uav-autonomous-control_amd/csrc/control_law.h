@@ -4,6 +4,12 @@
 
 #include "uavac_internal.h"
 
+// No implicit FMA contraction in the control law: every fused multiply-add is written as fma().  The
+// arithmetic is then the same instruction sequence in every kernel that inlines these functions (fused
+// rollout with or without logs, single tick, probes), which is what makes chunked / single-step / fused
+// runs bit-identical (tests/test_gpu_control.py).
+#pragma clang fp contract(off)
+
 namespace uavac_dev {
 
 constexpr double kPi = 3.141592653589793238462643383279502884;
@@ -17,6 +23,39 @@ __device__ __forceinline__ double floored_mod(double a, double b) {
     double r = fmod(a, b);
     if (r != 0.0 && r < 0.0) r += b;
     return r;
+}
+
+
+// ---- reduced-cost fp64 primitives for the per-tick path ------------------------------------------
+// v_rcp_f64 / v_rsq_f64 are ~2^-26 seeds; two Newton steps reach fp64 (<= 1-2 ulp).  No denormal /
+// special-case scaling: arguments on the per-tick path are normal, finite and positive by construction.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    double e = fma(-(hx * y), y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-(hx * y), y, 0.5);
+    return fma(y, e, y);
+}
+// sqrt(x) for x >= 0: Goldschmidt step on the rsq seed + one residual correction.  x is floored at the
+// smallest normal so that x == 0 needs no special case (returns 1.5e-154 instead of 0).
+__device__ __forceinline__ double fast_sqrt(double x) {
+    x = fmax(x, 2.2250738585072014e-308);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return g;
 }
 
 struct Rot { double r00, r01, r02, r10, r11, r12, r20, r21, r22; };
@@ -100,9 +139,9 @@ __device__ __forceinline__ void euler_trig(double q0, double q1, double q2, doub
 __device__ __forceinline__ void body_rate(const VehK &V, double pc, double qc, double rc, double wp, double wq,
                                           double wr, double &Mx, double &My, double &Mz) {
     const double Iwx = V.I[0] * wp, Iwy = V.I[1] * wq, Iwz = V.I[2] * wr;
-    Mx = V.ikp[0] * (pc - wp) + (wq * Iwz - wr * Iwy);
-    My = V.ikp[1] * (qc - wq) + (wr * Iwx - wp * Iwz);
-    Mz = V.ikp[2] * (rc - wr) + (wp * Iwy - wq * Iwx);
+    Mx = fma(V.ikp[0], pc - wp, fma(wq, Iwz, -(wr * Iwy)));
+    My = fma(V.ikp[1], qc - wq, fma(wr, Iwx, -(wp * Iwz)));
+    Mz = fma(V.ikp[2], rc - wr, fma(wp, Iwy, -(wq * Iwx)));
 }
 
 // Quad._allocate_rotor_forces (quad.py:105-122); rotor order FL, FR, RR, RL (quad.py:157-166)
@@ -115,26 +154,27 @@ __device__ __forceinline__ void allocate(const VehK &V, double thrust, double Mx
     mf[1] = (-pb + qb - rb) * 0.25;
     mf[2] = (-pb - qb + rb) * 0.25;
     mf[3] = (pb - qb - rb) * 0.25;
-    double lim = 1.0e300;
-    const double up = V.max_thrust - col, dn = V.min_thrust - col;
+    // moment_scale = clip(min_i limit_i, 0, 1), limit_i = (max-col)/mf_i for mf_i > 0, (min-col)/mf_i for
+    // mf_i < 0, 1 for mf_i == 0.  Both numerators are rotor independent, so the smallest limit on each side
+    // belongs to the largest |mf_i| of that sign; the two candidates are compared by cross-multiplication
+    // and only the winner is divided.  (The mf_i sum to zero: either both signs occur or all are zero.)
+    const double up = V.max_thrust - col, dn = col - V.min_thrust;            // both >= 0
+    const double mpos = fmax(fmax(mf[0], mf[1]), fmax(mf[2], mf[3]));          // >= 0
+    const double mneg = -fmin(fmin(mf[0], mf[1]), fmin(mf[2], mf[3]));         // >= 0
+    const bool pos_wins = up * mneg < dn * mpos;                               // up/mpos < dn/mneg
+    const double na = pos_wins ? up : dn, nb = pos_wins ? mpos : mneg;
+    const double sc = (na < nb) ? na * fast_rcp(nb) : 1.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double num = (mf[i] > 0.0) ? up : dn;
-        const double l = (mf[i] != 0.0) ? num / mf[i] : 1.0;
-        lim = fmin(lim, l);
-    }
-    const double sc = clampd(lim, 0.0, 1.0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = clampd(col + sc * mf[i], V.min_thrust, V.max_thrust);
+    for (int i = 0; i < 4; ++i) f[i] = clampd(fma(sc, mf[i], col), V.min_thrust, V.max_thrust);
 }
 
 // Quad.set_propeller_speed (quad.py:88-103): omega_cmd = sqrt(f/kf), first-order lag (rise / fall)
 __device__ __forceinline__ void motors(const VehK &V, const double f[4], double om[4], double omc[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        omc[i] = sqrt(f[i] * V.inv_kf);
+        omc[i] = fast_sqrt(f[i] * V.inv_kf);
         const double resp = (omc[i] > om[i]) ? V.resp_rise : V.resp_fall;
-        om[i] += resp * (omc[i] - om[i]);
+        om[i] = fma(resp, omc[i] - om[i], om[i]);
     }
 }
 
@@ -142,10 +182,11 @@ __device__ __forceinline__ void motors(const VehK &V, const double f[4], double 
 // Euler integrator, free joint):
 //   v' = g e3 - (T/m) R e3 ; w' = I^-1 (tau - w x I w) ; v += dt v' ; w += dt w' ; p += dt v_new ;
 //   q <- normalise(q (x) exp(dt w_new))
+// inv_n2 = 1/|q|^2 of the incoming attitude (exactly 1 when this function produced it).
 __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4], double &px, double &py,
                                                double &pz, double &q0, double &q1, double &q2, double &q3,
                                                double &vx, double &vy, double &vz, double &wp, double &wq,
-                                               double &wr) {
+                                               double &wr, double inv_n2) {
     const double f0 = V.kf * om[0] * om[0], f1 = V.kf * om[1] * om[1];
     const double f2 = V.kf * om[2] * om[2], f3 = V.kf * om[3] * om[3];
     const double T = f0 + f1 + f2 + f3;
@@ -153,33 +194,31 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
     const double ty = V.arm * (f0 + f1 - f2 - f3);
     const double tz = V.kappa * (-f0 + f1 - f2 + f3);
     {
-        const double inv_n2 = 1.0 / (q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);      // R e3 of the normalised q
-        const double bzx = 2.0 * (q1 * q3 + q0 * q2) * inv_n2;
-        const double bzy = 2.0 * (q2 * q3 - q0 * q1) * inv_n2;
-        const double bzz = 1.0 - 2.0 * (q1 * q1 + q2 * q2) * inv_n2;
-        const double tm = T * V.inv_mass;
-        vx += V.dt * (-tm * bzx);
-        vy += V.dt * (-tm * bzy);
-        vz += V.dt * (V.g - tm * bzz);
+        const double s2 = 2.0 * inv_n2;                               // R e3 of the normalised attitude
+        const double bzx = fma(q1, q3, q0 * q2) * s2;
+        const double bzy = fma(q2, q3, -(q0 * q1)) * s2;
+        const double bzz = fma(-s2, fma(q1, q1, q2 * q2), 1.0);
+        const double tm = T * V.inv_mass * V.dt;
+        vx = fma(-tm, bzx, vx);
+        vy = fma(-tm, bzy, vy);
+        vz = fma(V.dt, V.g, fma(-tm, bzz, vz));
     }
     {
         const double Jx = V.I[0] * wp, Jy = V.I[1] * wq, Jz = V.I[2] * wr;
-        const double cx = wq * Jz - wr * Jy, cy = wr * Jx - wp * Jz, cz = wp * Jy - wq * Jx;
-        wp += V.dt * ((tx - cx) * V.inv_I[0]);
-        wq += V.dt * ((ty - cy) * V.inv_I[1]);
-        wr += V.dt * ((tz - cz) * V.inv_I[2]);
+        const double cx = fma(wq, Jz, -(wr * Jy)), cy = fma(wr, Jx, -(wp * Jz)), cz = fma(wp, Jy, -(wq * Jx));
+        wp = fma(V.dt, (tx - cx) * V.inv_I[0], wp);
+        wq = fma(V.dt, (ty - cy) * V.inv_I[1], wq);
+        wr = fma(V.dt, (tz - cz) * V.inv_I[2], wr);
     }
-    px += V.dt * vx; py += V.dt * vy; pz += V.dt * vz;
+    px = fma(V.dt, vx, px); py = fma(V.dt, vy, py); pz = fma(V.dt, vz, pz);
     // dq = [cos h, sin(h) w/|w|], h = |w| dt / 2
-    const double w2 = wp * wp + wq * wq + wr * wr;
+    const double w2 = fma(wp, wp, fma(wq, wq, wr * wr));
     const double h2 = 0.25 * V.dt * V.dt * w2;
     double ch, sh_over;                           // cos(h), sin(h)/|w| = (dt/2) sinc(h)
-    if (h2 < 0.0625) {
-        // |h| < 0.25: Taylor series through h^14, truncation < 1e-19 relative
-        ch = 1.0 + h2 * (-1.0 / 2 + h2 * (1.0 / 24 + h2 * (-1.0 / 720 + h2 * (1.0 / 40320 + h2 * (-1.0 / 3628800 +
-             h2 * (1.0 / 479001600 + h2 * (-1.0 / 87178291200.0)))))));
-        const double sinc = 1.0 + h2 * (-1.0 / 6 + h2 * (1.0 / 120 + h2 * (-1.0 / 5040 + h2 * (1.0 / 362880 +
-             h2 * (-1.0 / 39916800 + h2 * (1.0 / 6227020800.0 + h2 * (-1.0 / 1307674368000.0)))))));
+    if (h2 < 1.0e-3) {
+        // |h| < 0.0316 (|w| < 63 rad/s at dt = 1 ms): Taylor series through h^8, truncation < 3e-22
+        ch = fma(h2, fma(h2, fma(h2, fma(h2, 1.0 / 40320, -1.0 / 720), 1.0 / 24), -0.5), 1.0);
+        const double sinc = fma(h2, fma(h2, fma(h2, fma(h2, 1.0 / 362880, -1.0 / 5040), 1.0 / 120), -1.0 / 6), 1.0);
         sh_over = 0.5 * V.dt * sinc;
     } else {
         const double wn = sqrt(w2), h = 0.5 * V.dt * wn;
@@ -187,11 +226,16 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
         sh_over = sin(h) / wn;
     }
     const double d1 = sh_over * wp, d2 = sh_over * wq, d3 = sh_over * wr;
-    const double n0 = q0 * ch - q1 * d1 - q2 * d2 - q3 * d3;
-    const double n1 = q0 * d1 + q1 * ch + q2 * d3 - q3 * d2;
-    const double n2 = q0 * d2 - q1 * d3 + q2 * ch + q3 * d1;
-    const double n3 = q0 * d3 + q1 * d2 - q2 * d1 + q3 * ch;
-    const double inv = 1.0 / sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+    const double n0 = fma(q0, ch, -fma(q1, d1, fma(q2, d2, q3 * d3)));
+    const double n1 = fma(q0, d1, fma(q1, ch, fma(q2, d3, -(q3 * d2))));
+    const double n2 = fma(q0, d2, fma(q2, ch, fma(q3, d1, -(q1 * d3))));
+    const double n3 = fma(q0, d3, fma(q3, ch, fma(q1, d2, -(q2 * d1))));
+    // |q (x) dq|^2 = |q|^2 (dq is unit to rounding), so e = n - 1 is ~1e-16 for a unit q and
+    // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 is exact to rounding; a non-unit q (first tick of a caller-supplied
+    // state) takes the general path.
+    const double e = fma(n0, n0, fma(n1, n1, fma(n2, n2, n3 * n3))) - 1.0;
+    double inv = fma(e, fma(e, 0.375, -0.5), 1.0);
+    if (fabs(e) > 1.0e-6) inv = fast_rsqrt(e + 1.0);
     q0 = n0 * inv; q1 = n1 * inv; q2 = n2 * inv; q3 = n3 * inv;
 }
 

@@ -121,7 +121,9 @@ __global__ void dynamics_step_kernel(const VehK V, double *__restrict__ state, i
     double X[13], om[4];
     for (int i = 0; i < 13; ++i) X[i] = state[i * sB + b];
     for (int i = 0; i < 4; ++i) om[i] = state[(13 + i) * sB + b];
-    free_body_step(V, om, X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11], X[12]);
+    const double qn2 = X[3] * X[3] + X[4] * X[4] + X[5] * X[5] + X[6] * X[6];
+    const double inv_n2 = (fabs(qn2 - 1.0) < 1.0e-12) ? 1.0 : 1.0 / qn2;
+    free_body_step(V, om, X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11], X[12], inv_n2);
     for (int i = 0; i < 13; ++i) state[i * sB + b] = X[i];
     if (aabbs && istate) {
         int hit = 0;
