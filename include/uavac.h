@@ -99,6 +99,11 @@ int uavac_minsnap_row_counts_dev(uavac_ctx *ctx, const double *wp, int B, int m,
  * status [B] i32 (may be NULL): 0 ok, 1 singular system. */
 int uavac_minsnap_solve_dev(uavac_ctx *ctx, const double *wp, const double *times, int B, int m,
                             double *coeffs, int32_t *status);
+/* The same QP through the other device solver: wave-per-mission banded LU with partial pivoting in LDS
+ * (uavac_minsnap_solve_dev is the lane-per-mission block-Thomas recurrence).  Kept as an independent,
+ * pivoted cross-check; ~50x slower. */
+int uavac_minsnap_solve_banded_dev(uavac_ctx *ctx, const double *wp, const double *times, int B, int m,
+                                   double *coeffs, int32_t *status);
 /* Sampler (:100-119) + yaw scan (_calculate_yaws :126-136). */
 int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
                              const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,

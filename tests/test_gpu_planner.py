@@ -260,3 +260,29 @@ def test_full_size_properties_config2(eng):
     # spot-check 4 missions against the oracle
     for b in (0, 1365, 2730, 4095):
         assert col_err(plan.mission(b), mo.plan(wps[b], 3.0, 0.01, method="solve")) < 1e-8
+
+
+@pytest.mark.parametrize("m, lo, hi, tol", [(1, 2.5, 3.5, 0.0), (2, 2.5, 3.5, 1e-11), (12, 2.5, 3.5, 1e-10),
+                                           (20, 1.0, 6.0, 1e-8), (64, 2.5, 3.5, 1e-9)])
+def test_two_device_solvers_agree(eng, m, lo, hi, tol):
+    """The lane-per-mission block-Thomas solver (the one the API uses) against the independent
+    wave-per-mission pivoted banded LU, on batches that are not a multiple of the wave size."""
+    import ctypes
+    import torch
+    from oracle import minsnap_oracle as mo
+    B = 203
+    wps = mo.synthetic_missions(B, m, lo, hi)
+    plan = eng.plan(wps, 3.0, 0.01)
+    eng.check(plan)
+    other = torch.empty_like(plan.coeffs)
+    status = torch.ones((B,), dtype=torch.int32, device=other.device)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    eng._bind_stream()
+    eng.ctx.call("uavac_minsnap_solve_banded_dev", P(plan.waypoints), P(plan.times), B, m, P(other), P(status))
+    torch.cuda.synchronize()
+    assert int(status.sum()) == 0
+    a, b = plan.coeffs.cpu().numpy().reshape(-1, 3), other.cpu().numpy().reshape(-1, 3)
+    # compare as trajectories at the knots' scale: coefficients of high powers are large, so normalise per mission
+    assert col_err(a, b) <= tol * max(1.0, np.abs(b).max())
+    ref = mo.plan(wps[B - 1], 3.0, 0.01, method="solve")
+    assert col_err(plan.mission(B - 1), ref) < 1e-6

@@ -6,17 +6,17 @@
 //                                                   valid subset, hold last valid, back-fill leading rows)
 //   np.hstack row assembly               :122-123
 //
-// One 256-thread workgroup per mission walks its rows in chunks of 256.  The kernel is a pure
-// HBM write stream (88 B per row): rows are evaluated one per lane (Horner, coefficients broadcast
-// from LDS), the yaw hold/unwrap is a wave-ballot + shuffle scan carried across chunks, and each
-// chunk is staged in LDS so that the row-major (N,11) output leaves as contiguous 16-byte stores.
+// One wavefront (64-thread workgroup) per mission walks its rows in chunks of 64, in a single pass and
+// without workgroup barriers.  The kernel is a pure HBM write stream (88 B per row): rows are evaluated one
+// per lane (Horner, coefficients broadcast from LDS), the yaw hold / unwrap / back-fill is a wave ballot +
+// shuffle scan carried across chunks in scalar registers, and each chunk is staged in LDS so that the
+// row-major (N,11) output leaves as contiguous 16-byte stores (5.6 KB per chunk).
 
 #include "uavac_internal.h"
 
 namespace {
 
-constexpr int SB = 256;                 // rows per chunk == threads per workgroup
-constexpr int NW = SB / 64;
+constexpr int SB = 64;                  // rows per chunk == threads per workgroup == one wavefront
 constexpr double kMinSpeedForYaw = 1e-3;   // MinimumSnap.MIN_HORIZONTAL_SPEED_FOR_YAW, minimum_snap.py:11
 constexpr double kPi = 3.141592653589793238462643383279502884;
 constexpr double kTwoPi = 2.0 * kPi;
@@ -50,62 +50,33 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     double *stage = lds;                         // [SB*11]
     double *cl = stage + SB * UAVAC_TRAJ_COLS;   // [24*m] coefficients of this mission
     int *pre = reinterpret_cast<int *>(cl + 24 * m);   // [m+1] exclusive prefix of seg_rows
-    __shared__ double w_ang[NW], w_sum[NW];
-    __shared__ int w_has[NW];
-    __shared__ double s_first_yaw;
-    __shared__ int s_first_row;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int64_t row0 = row_offsets[b];
     const int N = (int)(row_offsets[b + 1] - row0);
 
-    for (int i = tid; i < 24 * m; i += SB) cl[i] = coeffs[(size_t)b * 24 * m + i];
-    if (tid == 0) {
-        int acc = 0;
-        for (int s = 0; s < m; ++s) { pre[s] = acc; acc += seg_rows[(size_t)b * m + s]; }
-        pre[m] = acc;
-        s_first_row = N;
-        s_first_yaw = 0.0;
+    for (int i = lane; i < 24 * m; i += SB) cl[i] = coeffs[(size_t)b * 24 * m + i];
+    {   // exclusive prefix of the per-segment row counts: lane s holds segment s (m <= 64)
+        int v = (lane < m) ? seg_rows[(size_t)b * m + lane] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane < m) pre[lane] = inc - v;
+        if (lane == m - 1) pre[m] = inc;
     }
     __syncthreads();
 
-    // ---- pre-pass: first row whose horizontal speed is usable, and its heading (back-fill value) ----
-    {
-        int s = 0;
-        for (int c0 = 0; c0 < N; c0 += SB) {
-            int r = c0 + tid;
-            bool valid = false;
-            double vx = 0.0, vy = 0.0;
-            if (r < N) {
-                s = segment_of(pre, m, r, s);
-                double t = (double)(r - pre[s]) * dt;
-                const double *c = cl + s * 24;
-                vx = 7.0 * c[21]; vy = 7.0 * c[22];
-#pragma unroll
-                for (int i = 6; i >= 1; --i) { vx = vx * t + (double)i * c[3 * i]; vy = vy * t + (double)i * c[3 * i + 1]; }
-                valid = sqrt(vx * vx + vy * vy) >= kMinSpeedForYaw;
-            }
-            if (valid) atomicMin(&s_first_row, r);
-            __syncthreads();
-            int fr = s_first_row;
-            __syncthreads();
-            if (fr < N) {
-                if (r == fr) s_first_yaw = atan2(vy, vx);
-                break;
-            }
-        }
-        __syncthreads();
-    }
-    const int first_row = s_first_row;
-    const double first_yaw = s_first_yaw;
-
-    // ---- main pass ---------------------------------------------------------------------------------
+    // carried across chunks (wave-uniform): has a valid heading been seen, its raw angle, the running
+    // unwrap sum (np.cumsum of np.unwrap's corrections), and the heading used for the back-fill
     bool carry_has = false;
     double carry_ang = 0.0, carry_sum = 0.0;
     int s = 0;
     for (int c0 = 0; c0 < N; c0 += SB) {
-        const int r = c0 + tid;
+        const int r = c0 + lane;
         const bool active = r < N;
         double px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0, ax = 0, ay = 0, az = 0;
         if (active) {
@@ -129,74 +100,60 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                 }
             }
         }
-        // rows before first_row are never valid and first_row always is (decided once, in the pre-pass)
-        const bool valid = active && (r == first_row || (r > first_row && sqrt(vx * vx + vy * vy) >= kMinSpeedForYaw));
+        const bool valid = active && (sqrt(vx * vx + vy * vy) >= kMinSpeedForYaw);
         const double ang = valid ? atan2(vy, vx) : 0.0;
 
-        // last valid heading strictly before this row: in-wave via ballot, then earlier waves, then the carry
+        // last valid heading strictly before this row: inside the chunk via ballot, else the carry
         const unsigned long long mask = __ballot(valid);
         const unsigned long long lower = mask & ((1ull << lane) - 1ull);
         bool prev_has = lower != 0ull;
         double prev_ang = __shfl(ang, prev_has ? 63 - __clzll((long long)lower) : 0);
-        const double wlast = __shfl(ang, mask ? 63 - __clzll((long long)mask) : 0);
-        if (lane == 0) { w_has[wv] = mask != 0ull; w_ang[wv] = wlast; }
-        __syncthreads();
-        if (!prev_has) {
-            for (int w = wv - 1; w >= 0 && !prev_has; --w)
-                if (w_has[w]) { prev_has = true; prev_ang = w_ang[w]; }
-            if (!prev_has && carry_has) { prev_has = true; prev_ang = carry_ang; }
-        }
-        double corr = (valid && prev_has) ? unwrap_correction(ang - prev_ang) : 0.0;
-        // inclusive prefix sum of the corrections (np.cumsum) across the chunk, on top of the carry
-        double incl = corr;
+        if (!prev_has && carry_has) { prev_has = true; prev_ang = carry_ang; }
+        const double corr = (valid && prev_has) ? unwrap_correction(ang - prev_ang) : 0.0;
+        double incl = corr;                       // inclusive prefix sum of the corrections in this chunk
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const double o = __shfl_up(incl, d);
             if (lane >= d) incl += o;
         }
-        if (lane == 63) w_sum[wv] = incl;
-        __syncthreads();
-        double base = carry_sum;
-        for (int w = 0; w < wv; ++w) base += w_sum[w];
-        const double cum = base + incl;
+        const double cum = carry_sum + incl;
+        // rows before the mission's first valid heading take that heading (np.searchsorted(...)-1 clipped to 0)
+        const bool first_here = !carry_has && mask != 0ull;
+        const int first_lane = first_here ? __builtin_ctzll(mask) : 0;
+        const double first_yaw = __shfl(ang, first_lane);          // its unwrap sum is 0 by construction
         double yaw;
-        if (r < first_row) yaw = first_yaw;                  // also the all-invalid mission: zeros
-        else yaw = (valid ? ang : prev_ang) + cum;
-
-        // carries for the next chunk (uniform across the workgroup)
-        double tot = carry_sum;
-        bool any = false;
-        double lastang = carry_ang;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            tot += w_sum[w];
-            if (w_has[w]) { any = true; lastang = w_ang[w]; }
+        if (valid || prev_has) yaw = (valid ? ang : prev_ang) + cum;
+        else yaw = first_here ? first_yaw : 0.0;                   // 0 = placeholder, patched below if needed
+        if (first_here && c0 > 0) {
+            // the first usable heading arrived after whole chunks of placeholders: patch their yaw column
+            // (same wave, same addresses, program order => the later store wins)
+            for (int i = lane; i < c0; i += SB) traj[(row0 + i) * UAVAC_TRAJ_COLS + 9] = first_yaw;
         }
+        // carries (wave-uniform)
+        carry_sum += __shfl(incl, 63);
+        if (mask != 0ull) { carry_has = true; carry_ang = __shfl(ang, 63 - __clzll((long long)mask)); }
 
         if (active) {
-            double *o = stage + tid * UAVAC_TRAJ_COLS;
+            double *o = stage + lane * UAVAC_TRAJ_COLS;
             o[0] = px; o[1] = py; o[2] = pz; o[3] = vx; o[4] = vy; o[5] = vz;
             o[6] = ax; o[7] = ay; o[8] = az; o[9] = yaw; o[10] = (double)s;
         }
-        __syncthreads();
-        carry_sum = tot;
-        carry_has = carry_has || any;
-        carry_ang = lastang;
+        __syncthreads();                          // single wave: orders the LDS writes before the reads below
 
         // coalesced write-out of the staged chunk: 16-byte stores from an even element index
         const int nrows = min(SB, N - c0);
         const int nel = nrows * UAVAC_TRAJ_COLS;
         double *dst = traj + (row0 + c0) * UAVAC_TRAJ_COLS;
         const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-        if (head && tid == 0) dst[0] = stage[0];
+        if (head && lane == 0) dst[0] = stage[0];
         const int npairs = (nel - head) >> 1;
-        for (int p = tid; p < npairs; p += SB) {
+        for (int p = lane; p < npairs; p += SB) {
             double2 v;
             v.x = stage[head + 2 * p];
             v.y = stage[head + 2 * p + 1];
             *reinterpret_cast<double2 *>(dst + head + 2 * p) = v;
         }
-        if (((nel - head) & 1) && tid == 64) dst[nel - 1] = stage[nel - 1];
+        if (((nel - head) & 1) && lane == 63) dst[nel - 1] = stage[nel - 1];
         __syncthreads();
     }
 }

@@ -80,30 +80,53 @@ __global__ void row_counts_kernel(const double *__restrict__ wp, int B, int m, d
     if (bad) atomicOr(&flags[0], 1);
 }
 
-// Exclusive prefix sum of totals[B] -> row_offsets[B+1] (int64).  Single 1024-thread workgroup:
-// B <= 2^18 ints is a few hundred KB, two passes over it are negligible next to the sampler.
-__global__ void __launch_bounds__(1024) scan_totals_kernel(const int32_t *__restrict__ totals, int B,
-                                                          int64_t *__restrict__ row_offsets) {
-    __shared__ int64_t part[1024];
-    int tid = threadIdx.x;
-    int per = (B + 1023) / 1024;
-    int lo = tid * per, hi = min(lo + per, B);
-    int64_t s = 0;
-    for (int i = lo; i < hi; ++i) s += totals[i];
-    part[tid] = s;
+// Exclusive prefix sum of totals[B] -> row_offsets[B+1] (int64), two levels, every access coalesced:
+// (1) per-256 tile sums, (2) one workgroup scans the tile sums, (3) each tile scans itself on top of its base.
+__device__ __forceinline__ int64_t block_inclusive_scan_256(int64_t v, int64_t *wsum /* [4] shared */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    if (lane == 63) wsum[wv] = v;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int64_t v = (tid >= d) ? part[tid - d] : 0;
+    int64_t base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    return v + base;
+}
+
+__global__ void __launch_bounds__(256) tile_sums_kernel(const int32_t *__restrict__ totals, int B,
+                                                        int64_t *__restrict__ tile_sum) {
+    __shared__ int64_t wsum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int64_t inc = block_inclusive_scan_256(i < B ? totals[i] : 0, wsum);
+    if (threadIdx.x == 255) tile_sum[blockIdx.x] = inc;
+}
+
+__global__ void __launch_bounds__(256) scan_tiles_kernel(int64_t *__restrict__ tile_sum, int n_tiles) {
+    __shared__ int64_t wsum[4];
+    int64_t carry = 0;
+    for (int t0 = 0; t0 < n_tiles; t0 += 256) {
+        const int i = t0 + threadIdx.x;
+        const int64_t v = i < n_tiles ? tile_sum[i] : 0;
+        const int64_t inc = block_inclusive_scan_256(v, wsum);
+        if (i < n_tiles) tile_sum[i] = carry + inc - v;          // exclusive base of tile i
         __syncthreads();
-        part[tid] += v;
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
-    int64_t run = part[tid] - s;
-    for (int i = lo; i < hi; ++i) {
-        row_offsets[i] = run;
-        run += totals[i];
-    }
-    if (tid == 1023) row_offsets[B] = part[1023];
+}
+
+__global__ void __launch_bounds__(256) tile_offsets_kernel(const int32_t *__restrict__ totals, int B,
+                                                           const int64_t *__restrict__ tile_base,
+                                                           int64_t *__restrict__ row_offsets) {
+    __shared__ int64_t wsum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int64_t v = i < B ? totals[i] : 0;
+    const int64_t inc = block_inclusive_scan_256(v, wsum) + tile_base[blockIdx.x];
+    if (i < B) row_offsets[i] = inc - v;
+    if (i == B - 1) row_offsets[B] = inc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -299,16 +322,24 @@ __global__ void __launch_bounds__(64) minsnap_solve_kernel(const double *__restr
 
 int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                             double *times, int32_t *seg_rows, int64_t *row_offsets) {
+    const int n_tiles = (B + 255) / 256;
     if ((size_t)B > ctx->totals_cap) {
         if (ctx->d_totals) UAVAC_HIP(ctx, hipFree(ctx->d_totals));
         ctx->d_totals = nullptr;
         ctx->totals_cap = 0;
-        UAVAC_HIP(ctx, hipMalloc(&ctx->d_totals, sizeof(int32_t) * (size_t)B));
+        // totals [B] i32 followed by the tile sums [ceil(B/256)] i64 (8-byte aligned offset)
+        const size_t bytes = (((size_t)B * 4 + 7) & ~(size_t)7) + (size_t)n_tiles * 8;
+        UAVAC_HIP(ctx, hipMalloc(&ctx->d_totals, bytes));
         ctx->totals_cap = (size_t)B;
     }
-    hipLaunchKernelGGL(row_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, wp, B, m, velocity, dt,
+    int64_t *tiles = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ctx->d_totals) +
+                                                 (((size_t)ctx->totals_cap * 4 + 7) & ~(size_t)7));
+    hipLaunchKernelGGL(row_counts_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, wp, B, m, velocity, dt,
                        times, seg_rows, ctx->d_totals, ctx->d_flags);
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_totals, B, row_offsets);
+    hipLaunchKernelGGL(tile_sums_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, tiles, n_tiles);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles,
+                       row_offsets);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

@@ -104,6 +104,7 @@ void uavac_destroy(uavac_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_totals) (void)hipFree(ctx->d_totals);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -156,6 +157,13 @@ int uavac_minsnap_row_counts_dev(uavac_ctx *ctx, const double *wp, int B, int m,
 
 int uavac_minsnap_solve_dev(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                             int32_t *status) {
+    if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
+    if (!times || !coeffs) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    return uavac_launch_solve_bt(ctx, wp, times, B, m, coeffs, status);
+}
+
+int uavac_minsnap_solve_banded_dev(uavac_ctx *ctx, const double *wp, const double *times, int B, int m,
+                                   double *coeffs, int32_t *status) {
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
     if (!times || !coeffs) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     return uavac_launch_solve(ctx, wp, times, B, m, coeffs, status);
@@ -213,7 +221,7 @@ int uavac_minsnap_solve(uavac_ctx *ctx, const double *wp, int B, int m, double v
     // dt only shapes the row counts, which this entry point does not return
     if (int rc = uavac_launch_row_counts(ctx, dwp.as<double>(), B, m, velocity, 1.0, dt_.as<double>(),
                                          dsr.as<int32_t>(), dro.as<int64_t>())) return rc;
-    if (int rc = uavac_launch_solve(ctx, dwp.as<double>(), dt_.as<double>(), B, m, dco.as<double>(), nullptr)) return rc;
+    if (int rc = uavac_launch_solve_bt(ctx, dwp.as<double>(), dt_.as<double>(), B, m, dco.as<double>(), nullptr)) return rc;
     UAVAC_HIP(ctx, hipMemcpyAsync(coeffs, dco.p, nco * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (times) UAVAC_HIP(ctx, hipMemcpyAsync(times, dt_.p, nseg * 8, hipMemcpyDeviceToHost, ctx->stream));
     int32_t fl[4];

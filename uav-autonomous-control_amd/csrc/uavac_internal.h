@@ -16,6 +16,8 @@ struct uavac_ctx {
     int32_t *d_flags = nullptr;      // [4] device-side error flags (0: non-finite input, 1: singular system)
     int32_t *d_totals = nullptr;     // scratch for the row-count scan
     size_t totals_cap = 0;
+    double *d_ws = nullptr;          // block-Thomas workspace [m-1][28][B]
+    size_t ws_cap = 0;               // in doubles
     std::string err;
 };
 
@@ -53,6 +55,8 @@ int uavac_check_vehicle(uavac_ctx *ctx, const uavac_vehicle *V);
 // launchers (one per .hip file)
 int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                             double *times, int32_t *seg_rows, int64_t *row_offsets);
+int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
+                          int32_t *status);
 int uavac_launch_solve(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                        int32_t *status);
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
