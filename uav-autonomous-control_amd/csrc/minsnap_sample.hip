@@ -37,6 +37,12 @@ __device__ __forceinline__ double unwrap_correction(double dd) {
     return corr;
 }
 
+// double held by lane `l` (wave-uniform index): two v_readlane instead of two LDS-pipe bpermutes
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ int segment_of(const int *__restrict__ pre, int m, int r, int s) {
     while (s + 1 < m && r >= pre[s + 1]) ++s;
     return s;
@@ -111,16 +117,18 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
         if (!prev_has && carry_has) { prev_has = true; prev_ang = carry_ang; }
         const double corr = (valid && prev_has) ? unwrap_correction(ang - prev_ang) : 0.0;
         double incl = corr;                       // inclusive prefix sum of the corrections in this chunk
+        if (__ballot(corr != 0.0) != 0ull) {      // headings rarely wrap: most chunks skip the scan
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
+            for (int d = 1; d < 64; d <<= 1) {
+                const double o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
         }
         const double cum = carry_sum + incl;
         // rows before the mission's first valid heading take that heading (np.searchsorted(...)-1 clipped to 0)
         const bool first_here = !carry_has && mask != 0ull;
         const int first_lane = first_here ? __builtin_ctzll(mask) : 0;
-        const double first_yaw = __shfl(ang, first_lane);          // its unwrap sum is 0 by construction
+        const double first_yaw = lane_value(ang, first_lane);       // its unwrap sum is 0 by construction
         double yaw;
         if (valid || prev_has) yaw = (valid ? ang : prev_ang) + cum;
         else yaw = first_here ? first_yaw : 0.0;                   // 0 = placeholder, patched below if needed
@@ -130,8 +138,8 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             for (int i = lane; i < c0; i += SB) traj[(row0 + i) * UAVAC_TRAJ_COLS + 9] = first_yaw;
         }
         // carries (wave-uniform)
-        carry_sum += __shfl(incl, 63);
-        if (mask != 0ull) { carry_has = true; carry_ang = __shfl(ang, 63 - __clzll((long long)mask)); }
+        carry_sum += lane_value(incl, 63);
+        if (mask != 0ull) { carry_has = true; carry_ang = lane_value(ang, 63 - __clzll((long long)mask)); }
 
         if (active) {
             double *o = stage + lane * UAVAC_TRAJ_COLS;
