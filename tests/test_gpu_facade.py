@@ -199,3 +199,18 @@ def test_facade_closed_loop_matches_reference_golden(quad):
     assert col_err(clog[:200], g["lab_v2_cmd_first200"]) < 1e-9
     assert col_err(slog[9::10], g["lab_v2_state_every10"][:K // 10]) < 1e-5
     assert col_err(clog[9::10], g["lab_v2_cmd_every10"][:K // 10]) < 1e-5
+
+
+def test_lab_mission_from_scene_meets_reference_integration_bounds():
+    """Upstream tests/integration/test_mujoco_trajectory_tracking.py:11-36 (v = 2 m/s, dt = 0.01, F = 10) in
+    free flight: scene reader -> obstacle-aware plan -> one fused rollout with the AABB flag."""
+    import os
+    from conftest import GOLDEN
+    from uav_ac.main import fly_mission
+    out = fly_mission(os.path.join(GOLDEN, "lab_scene_min.xml"), velocity=2.0, frequency=10)
+    g = load_golden("closed_loop.npz")
+    assert out["trajectory"].shape == g["lab_v2_traj"].shape
+    assert col_err(out["trajectory"], g["lab_v2_traj"]) < 1e-5
+    assert out["distance_to_goal"] < 0.5 and out["goal_reached"]
+    assert out["mean_tracking_error"] < 0.5
+    assert out["collision_detected"] is False

@@ -96,3 +96,62 @@ def _generate_mission_trajectory(waypoints: np.ndarray, obstacles, velocity: flo
     takeoff = MinimumSnap(waypoints[:2], obstacles, velocity, dt).get_trajectory()
     course = MinimumSnap(waypoints[1:], obstacles, velocity, dt).get_trajectory()
     return np.vstack((takeoff, course))
+
+
+def fly_mission(model_path, velocity: float = 3.0, frequency: int = 10, min_distance_target: float = 0.5,
+                settle_ticks: int = 2000):
+    """Head-less equivalent of the reference's `main()` (main.py:87-120) in free flight: read the scene,
+    plan takeoff + course around its obstacles, fly it, report.  The whole flight is ONE fused rollout on the
+    GPU (B = 1) with the per-tick AABB flag; no viewer, no ground contact.
+
+    Returns a dict: trajectory (N,11), states (K,13), distance_to_goal, goal_reached, collision_detected,
+    mean_tracking_error.
+    """
+    from .fleet import Engine
+    from .simulation.mujoco_sim import MujocoSimulation
+
+    sim = MujocoSimulation(model_path)
+    quad = sim.quad
+    dt_traj = quad.dt * frequency
+    trajectory = _generate_mission_trajectory(sim.mission_waypoints, sim.obstacles, velocity, dt_traj)
+
+    eng = Engine()
+    torch = eng._torch
+    rows = torch.as_tensor(trajectory, dtype=torch.float64, device=eng.device).contiguous()
+    offsets = torch.tensor([0, len(trajectory)], dtype=torch.int64, device=eng.device)
+    V = vehicle_from(quad, dt_outer=dt_traj)
+    V.inner_per_outer = int(frequency)
+    state = torch.zeros((nat.STATE_ROWS, 1), dtype=torch.float64, device=eng.device)
+    state[0:13, 0] = torch.as_tensor(quad.X)
+    istate = torch.zeros((3, 1), dtype=torch.int32, device=eng.device)
+    K = len(trajectory) * frequency + settle_ticks
+    log = torch.empty((K, 13, 1), dtype=torch.float64, device=eng.device)
+    aabbs = torch.as_tensor(sim.obstacles, dtype=torch.float64, device=eng.device).contiguous()
+    P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    eng._bind_stream()
+    eng.ctx.call("uavac_control_rollout_dev", C.byref(V), P(rows), P(offsets), P(state), P(istate), 1, K, P(log), None,
+                 P(aabbs), int(aabbs.shape[0]))
+    states = log[:, :, 0].cpu().numpy()
+    quad.X = state[0:13, 0].cpu().numpy()
+    n = min(len(trajectory), K // frequency)
+    err = np.linalg.norm(states[::frequency][:n, 0:3] - trajectory[:n, 0:3], axis=1)
+    dist = float(np.linalg.norm(quad.position - sim.goal_position))
+    return {"trajectory": trajectory, "states": states, "distance_to_goal": dist,
+            "goal_reached": dist < min_distance_target, "collision_detected": bool(istate[2, 0].item()),
+            "mean_tracking_error": float(err.mean())}
+
+
+def main(model_path=None) -> None:
+    import sys
+    path = model_path or (sys.argv[1] if len(sys.argv) > 1 else None)
+    if path is None:
+        raise SystemExit("usage: python -m uav_ac.main <scene.xml>")
+    out = fly_mission(path)
+    print(f"Flight finished {out['distance_to_goal']:.2f} m away from the goal "
+          f"({'reached' if out['goal_reached'] else 'missed'}).")
+    if out["collision_detected"]:
+        print("At least one collision occurred during the flight.")
+
+
+if __name__ == "__main__":
+    main()
