@@ -108,6 +108,13 @@ int uavac_minsnap_solve_banded_dev(uavac_ctx *ctx, const double *wp, const doubl
 int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
                              const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                              double dt, double *traj);
+/* Sampler that also reports, per mission and spline, whether any sampled position lies inside the cuboid
+ * aabb[6] = xmin xmax ymin ymax zmin zmax (device pointer; inclusive test of is_collision_cuboid :327-357):
+ * hit [B][m] i32 (0/1).  This is the collision scan of _generate_collision_free_trajectory (:81-87), fused
+ * into the sampling pass; the midpoint insertion that follows (:91-92) is host logic. */
+int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
+                                  const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
+                                  double dt, double *traj, const double *aabb, int32_t *hit);
 
 /* Host-pointer twins (synchronous). */
 int uavac_minsnap_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity,

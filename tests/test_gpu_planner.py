@@ -286,3 +286,51 @@ def test_two_device_solvers_agree(eng, m, lo, hi, tol):
     assert col_err(a, b) <= tol * max(1.0, np.abs(b).max())
     ref = mo.plan(wps[B - 1], 3.0, 0.01, method="solve")
     assert col_err(plan.mission(B - 1), ref) < 1e-6
+
+
+def test_batched_obstacle_replan_matches_reference_and_oracle(eng):
+    """SURVEY.md 8(f) N1, batched: ragged missions through the lab course's four AABBs at once.  Missions 0/1
+    are pinned by the reference's goldens (lab course, in-tree obstacle case); the others by the oracle's
+    restatement of the same loop.  The collision scan runs inside the sampler (uavac_minsnap_sample_hits_dev)."""
+    from oracle import minsnap_oracle as mo
+    g = load_golden("fixed_missions.npz")
+    aabbs = g["lab_aabbs"]
+    # perturbed lab courses that need one midpoint each (found with the oracle; both of its KKT paths agree on
+    # them -- where inserted midpoints make splines very short the reference's lstsq is rounding noise, SURVEY 0-F5)
+    extra = [np.array(w) for w in (
+        [[0.306, 7.421, -1.929], [4.879, 7.283, -1.507], [8.514, 4.336, -2.852], [10.092, 7.381, -2.899],
+         [14.786, 9.099, -1.907], [18.137, 10.603, -3.359], [19.445, 6.362, -1.644], [23.193, 7.388, -2.316]],
+        [[0.053, 8.505, -1.008], [4.813, 6.709, -2.036], [8.411, 2.449, -3.085], [10.596, 7.133, -3.169],
+         [14.558, 8.486, -2.093], [15.624, 10.454, -3.402], [19.668, 6.598, -1.978], [22.966, 7.643, -1.673]],
+        [[1.162, 6.984, -1.939], [2.316, 6.934, -1.926], [7.956, 3.78, -2.785], [10.762, 8.079, -3.215],
+         [15.071, 10.071, -2.944], [15.98, 9.633, -3.08], [20.045, 8.744, -1.429], [23.327, 7.061, -2.537]],
+        [[0.781, 7.554, -0.895], [4.809, 6.475, -1.561], [7.306, 2.632, -2.75], [9.763, 6.745, -3.247],
+         [14.376, 9.532, -2.248], [17.526, 8.708, -3.414], [20.748, 7.1, -1.595], [22.743, 8.334, -2.255]])]
+    extra += [g["lab_wp"][1:] + np.array([0.0, 0.2, -0.1]), g["lab_wp"][1:6] + np.array([0.1, -0.1, 0.0])]
+    missions = [g["lab_wp"][1:], g["lab_wp"][:2]] + extra
+    rp = eng.plan_collision_free(missions, aabbs, 3.0, 0.01)
+    assert rp.B == len(missions) and int(rp.row_offsets[-1]) == rp.total_rows
+    assert np.array_equal(rp.final_waypoints[0], g["lab_course_final_wp"])
+    ref_obs = g["lab_traj_obs"]                            # takeoff rows, then the course rows
+    n_takeoff = len(rp.mission(1))
+    assert col_err(rp.mission(1), ref_obs[:n_takeoff]) < TOL
+    assert col_err(rp.mission(0), ref_obs[n_takeoff:]) < TOL
+    grew = 0
+    for b, wp in enumerate(missions):
+        traj, final_wp = mo.plan_collision_free(wp, aabbs, 3.0, 0.01, method="solve")
+        assert np.array_equal(rp.final_waypoints[b], final_wp)
+        assert col_err(rp.mission(b), traj) < 1e-6
+        grew += len(final_wp) > len(wp)
+        p = rp.mission(b)[:, :3]
+        c = aabbs[-1]                                      # the last cuboid is guaranteed clean (earlier ones are not re-checked)
+        assert not np.any((p[:, 0] >= c[0]) & (p[:, 0] <= c[1]) & (p[:, 1] >= c[2]) & (p[:, 1] <= c[3]) &
+                          (p[:, 2] >= c[4]) & (p[:, 2] <= c[5]))
+    assert grew >= 4                                        # the case really inserts midpoints
+    # the in-tree obstacle case of the reference (tests/unit/planning/test_minimum_snap.py:171-183)
+    one = eng.plan_collision_free([g["obs_case_wp"]], g["obs_case_aabb"], 2.0, 0.01)
+    assert np.array_equal(one.final_waypoints[0], g["obs_case_final_wp"])
+    assert col_err(one.mission(0), g["obs_case_traj"]) < TOL
+    # a ragged plan flies like any other
+    fleet = eng.fleet(rp)
+    fleet.rollout(500)
+    assert bool((fleet.trajectory_index == 50).all())

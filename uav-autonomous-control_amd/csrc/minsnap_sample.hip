@@ -48,10 +48,12 @@ __device__ __forceinline__ int segment_of(const int *__restrict__ pre, int m, in
     return s;
 }
 
+template <bool HITS>
 __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__restrict__ coeffs,
                                                            const int32_t *__restrict__ seg_rows,
                                                            const int64_t *__restrict__ row_offsets, int B, int m,
-                                                           double dt, double *__restrict__ traj) {
+                                                           double dt, double *__restrict__ traj,
+                                                           const double *__restrict__ aabb, int32_t *__restrict__ hit) {
     extern __shared__ double lds[];
     double *stage = lds;                         // [SB*11]
     double *cl = stage + SB * UAVAC_TRAJ_COLS;   // [24*m] coefficients of this mission
@@ -105,6 +107,12 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                     ax = ax * t + f * c0x; ay = ay * t + f * c0y; az = az * t + f * c0z;
                 }
             }
+        }
+        if (HITS) {
+            // inclusive AABB test on the sampled position (minimum_snap.py:327-357); flags the row's spline
+            const bool in = active && px >= aabb[0] && px <= aabb[1] && py >= aabb[2] && py <= aabb[3] &&
+                            pz >= aabb[4] && pz <= aabb[5];
+            if (in) atomicOr(&hit[(size_t)b * m + s], 1);
         }
         const bool valid = active && (sqrt(vx * vx + vy * vy) >= kMinSpeedForYaw);
         const double ang = valid ? atan2(vy, vx) : 0.0;
@@ -169,10 +177,16 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
 }  // namespace
 
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
-                        int B, int m, double dt, double *traj) {
+                        int B, int m, double dt, double *traj, const double *aabb, int32_t *hit) {
     size_t lds = sizeof(double) * ((size_t)SB * UAVAC_TRAJ_COLS + (size_t)24 * m) + sizeof(int) * (size_t)(m + 2);
-    hipLaunchKernelGGL(minsnap_sample_kernel, dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows, row_offsets, B,
-                       m, dt, traj);
+    if (aabb && hit) {
+        UAVAC_HIP(ctx, hipMemsetAsync(hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
+        hipLaunchKernelGGL(minsnap_sample_kernel<true>, dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows,
+                           row_offsets, B, m, dt, traj, aabb, hit);
+    } else {
+        hipLaunchKernelGGL(minsnap_sample_kernel<false>, dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows,
+                           row_offsets, B, m, dt, traj, aabb, hit);
+    }
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

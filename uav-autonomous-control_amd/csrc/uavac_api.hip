@@ -178,6 +178,16 @@ int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double 
     return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj);
 }
 
+int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const double *times, const int32_t *seg_rows,
+                                  const int64_t *row_offsets, int B, int m, double dt, double *traj,
+                                  const double *aabb, int32_t *hit) {
+    (void)times;
+    if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
+    if (!seg_rows || !row_offsets || !traj || !aabb || !hit) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, aabb, hit);
+}
+
 // --------------------------------------------------------------------------------- planning, host
 int uavac_minsnap_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                              double *times, int32_t *seg_rows, int64_t *row_offsets) {

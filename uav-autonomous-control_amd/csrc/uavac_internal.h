@@ -60,7 +60,7 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
 int uavac_launch_solve(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                        int32_t *status);
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
-                        int B, int m, double dt, double *traj);
+                        int B, int m, double dt, double *traj, const double *aabb = nullptr, int32_t *hit = nullptr);
 int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positions, int B, int hover, double *state,
                             int32_t *istate);
 int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,

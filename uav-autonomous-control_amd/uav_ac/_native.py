@@ -62,6 +62,7 @@ _SIGNATURES = {
     "uavac_minsnap_solve_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "uavac_minsnap_solve_banded_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "uavac_minsnap_sample_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P]),
+    "uavac_minsnap_sample_hits_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
     "uavac_minsnap_row_counts": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
     "uavac_minsnap_solve": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_minsnap_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),

@@ -55,6 +55,24 @@ class Plan:
         return self.B * (24 * (self.m + 1) + 192 * self.m) + 88 * self.total_rows
 
 
+@dataclass
+class RaggedPlan:
+    """Trajectories of B missions whose segment counts differ (after obstacle-driven midpoint insertion).
+    Has what `Fleet` needs from a Plan: traj, row_offsets, start positions."""
+    B: int
+    velocity: float
+    dt: float
+    final_waypoints: list            # B host arrays (m_b + 1, 3): the waypoint lists after insertion
+    row_offsets: "object"            # (B+1,) i64
+    traj: "object"                   # (N, 11) f64
+    total_rows: int
+    start_positions: "object"        # (B, 3) f64
+
+    def mission(self, b: int) -> np.ndarray:
+        ro = self.row_offsets[b:b + 2].cpu().numpy()
+        return self.traj[int(ro[0]):int(ro[1])].cpu().numpy().copy()
+
+
 class Engine:
     """One GPU, one `uavac_ctx`.  Kernels are enqueued on torch's current stream for that device."""
 
@@ -103,6 +121,111 @@ class Engine:
         self.sample(plan)
         return plan
 
+    def plan_collision_free(self, waypoints, obstacles, velocity: float = 1.0, dt: float = 0.01,
+                            max_iterations: int = 64) -> RaggedPlan:
+        """Batched `MinimumSnap(path, obstacles, velocity, dt).get_trajectory()` with obstacles
+        (minimum_snap.py:63-95) for B missions at once.
+
+        Per mission the reference's semantics are kept: obstacles are visited in order; for each one the mission is
+        planned, every spline with a sample inside the cuboid gets a midpoint inserted before its end waypoint,
+        and it is re-planned until clean; earlier obstacles are not re-checked.  Here all missions advance
+        together: each round plans every still-active mission (grouped by segment count) and the sampler itself
+        reports the hit splines (`uavac_minsnap_sample_hits_dev`); only the midpoint insertion is host work.
+        `waypoints`: (B, m+1, 3) array or a list of (m_b+1, 3) arrays.  The loop is bounded (the reference's is
+        not: it cannot end when a waypoint lies inside a cuboid).
+        """
+        torch = self._torch
+        wps = [np.ascontiguousarray(w, dtype=np.float64) for w in waypoints]
+        B = len(wps)
+        if B == 0 or any(w.ndim != 2 or w.shape[1] != 3 or w.shape[0] < 2 for w in wps):
+            raise ValueError("waypoints must be B arrays of shape (m+1, 3)")
+        cuboids = np.zeros((0, 6)) if obstacles is None else np.asarray(obstacles, dtype=np.float64).reshape(-1, 6)
+        source = [None] * B                                    # mission -> (group Plan, index inside it)
+
+        def run_round(ids, cub):
+            groups = {}
+            for b in ids:
+                groups.setdefault(wps[b].shape[0] - 1, []).append(b)
+            again = []
+            for m, members in sorted(groups.items()):
+                if m > nat.MAX_SEGMENTS:
+                    raise RuntimeError(f"obstacle correction needs more than {nat.MAX_SEGMENTS} splines")
+                plan, hit = self._plan_group(np.stack([wps[b] for b in members]), velocity, dt, cub)
+                for j, b in enumerate(members):
+                    source[b] = (plan, j)
+                if hit is not None:
+                    hit = hit.cpu().numpy().astype(bool)
+                    for j in np.flatnonzero(hit.any(axis=1)):
+                        b = members[j]
+                        idx = np.flatnonzero(hit[j]) + 1              # spline s -> insert before waypoint s+1
+                        mids = (wps[b][idx - 1] + wps[b][idx]) / 2
+                        wps[b] = np.insert(wps[b], idx, mids, axis=0)
+                        again.append(b)
+            return again
+
+        if len(cuboids) == 0:
+            run_round(list(range(B)), None)
+        for cub in cuboids:
+            active = list(range(B))
+            for _ in range(max_iterations + 1):
+                if not active:
+                    break
+                active = run_round(active, cub)
+            else:
+                raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
+
+        # stitch the final trajectories together in mission order
+        nrows = torch.zeros((B,), dtype=torch.int64, device=self.device)
+        by_plan = {}
+        for b, (plan, j) in enumerate(source):
+            by_plan.setdefault(id(plan), (plan, [], []))
+            by_plan[id(plan)][1].append(b)
+            by_plan[id(plan)][2].append(j)
+        parts = []
+        for plan, ids, js in by_plan.values():
+            ids_t = torch.as_tensor(ids, device=self.device)
+            js_t = torch.as_tensor(js, device=self.device)
+            length = (plan.row_offsets[1:] - plan.row_offsets[:-1])[js_t]
+            nrows[ids_t] = length
+            parts.append((plan, ids_t, js_t, length))
+        offsets = torch.zeros((B + 1,), dtype=torch.int64, device=self.device)
+        offsets[1:] = torch.cumsum(nrows, 0)
+        total = int(offsets[-1].item())
+        traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, device=self.device)
+        for plan, ids_t, js_t, length in parts:
+            rep = torch.repeat_interleave(torch.arange(len(js_t), device=self.device), length)
+            within = torch.arange(int(length.sum().item()), device=self.device) - (torch.cumsum(length, 0) - length)[rep]
+            traj[offsets[ids_t][rep] + within] = plan.traj[plan.row_offsets[js_t][rep] + within]
+        starts = torch.as_tensor(np.stack([w[0] for w in wps]), dtype=torch.float64, device=self.device)
+        return RaggedPlan(B, float(velocity), float(dt), wps, offsets, traj, total, starts)
+
+    def _plan_group(self, wp_host, velocity, dt, cuboid):
+        """Plan one group of equal-m missions; with a cuboid also return the (B, m) hit flags."""
+        torch = self._torch
+        if cuboid is None:
+            return self.plan(wp_host, velocity, dt), None
+        wp = self._dev(wp_host, torch.float64)
+        B, m = int(wp.shape[0]), int(wp.shape[1]) - 1
+        kw = dict(device=self.device)
+        times = torch.empty((B, m), dtype=torch.float64, **kw)
+        seg_rows = torch.empty((B, m), dtype=torch.int32, **kw)
+        row_offsets = torch.empty((B + 1,), dtype=torch.int64, **kw)
+        coeffs = torch.empty((B, 8 * m, 3), dtype=torch.float64, **kw)
+        status = torch.zeros((B,), dtype=torch.int32, **kw)
+        hit = torch.empty((B, m), dtype=torch.int32, **kw)
+        aabb = self._dev(np.asarray(cuboid, dtype=np.float64).reshape(6), torch.float64)
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_row_counts_dev", _ptr(wp), B, m, float(velocity), float(dt), _ptr(times),
+                      _ptr(seg_rows), _ptr(row_offsets))
+        self.ctx.call("uavac_minsnap_solve_dev", _ptr(wp), _ptr(times), B, m, _ptr(coeffs), _ptr(status))
+        total = int(row_offsets[-1].item())
+        traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
+        self.ctx.call("uavac_minsnap_sample_hits_dev", _ptr(coeffs), _ptr(times), _ptr(seg_rows), _ptr(row_offsets),
+                      B, m, float(dt), _ptr(traj), _ptr(aabb), _ptr(hit))
+        plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total)
+        self.check(plan)
+        return plan, hit
+
     def solve(self, plan: Plan):
         """Re-run times/row counts + coefficient solve into plan's buffers (no allocation, no sync)."""
         self._bind_stream()
@@ -140,8 +263,12 @@ class Fleet:
         self.state = torch.empty((nat.STATE_ROWS, self.B), dtype=torch.float64, device=engine.device)
         self.istate = torch.empty((nat.ISTATE_ROWS, self.B), dtype=torch.int32, device=engine.device)
         self._hover = bool(hover)
-        self._positions = (engine._dev(positions, torch.float64) if positions is not None
-                           else plan.waypoints[:, 0, :].contiguous())
+        if positions is not None:
+            self._positions = engine._dev(positions, torch.float64)
+        elif hasattr(plan, "start_positions"):
+            self._positions = plan.start_positions.contiguous()
+        else:
+            self._positions = plan.waypoints[:, 0, :].contiguous()
         self.reset()
 
     def reset(self):

@@ -17,6 +17,9 @@ from .. import _native as nat
 from .._single import ctx
 
 
+_ENGINE = None          # lazily created device engine for the obstacle loop
+
+
 class MinimumSnap:
     START_END_TIME_FACTOR = 1.5                 # reference minimum_snap.py:10 (applied inside the kernel)
     MIN_HORIZONTAL_SPEED_FOR_YAW = 1e-3         # reference minimum_snap.py:11 (applied inside the kernel)
@@ -87,21 +90,15 @@ class MinimumSnap:
             self.reset()
             self._generate_trajectory()
             return
-        for cub in np.asarray(self.coord_obstacles, dtype=float).reshape(-1, 6):
-            self.reset()
-            traj = self._generate_trajectory()
-            for _ in range(self.MAX_REPLAN_ITERATIONS):
-                p = traj[:, :3]
-                hit = ((p[:, 0] >= cub[0]) & (p[:, 0] <= cub[1]) & (p[:, 1] >= cub[2]) & (p[:, 1] <= cub[3]) &
-                       (p[:, 2] >= cub[4]) & (p[:, 2] <= cub[5]))
-                ids = {int(s) + 1 for s in np.unique(traj[hit, 10])}
-                if not ids:
-                    break
-                self.reset()
-                self.waypoints = MinimumSnap.insert_midpoints_at_indexes(self.waypoints, ids)
-                traj = self._generate_trajectory()
-            else:
-                raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
+        from ..fleet import Engine
+        global _ENGINE
+        if _ENGINE is None:
+            _ENGINE = Engine()
+        rp = _ENGINE.plan_collision_free([nat.as_f64(self.waypoints)], self.coord_obstacles, self.velocity, self.dt,
+                                         max_iterations=self.MAX_REPLAN_ITERATIONS)
+        self.reset()
+        self.waypoints = rp.final_waypoints[0]
+        self._generate_trajectory()              # fills times / coeffs / A / b for the final waypoint list
 
     # ------------------------------------------------------- inspection helpers (host, not on the GPU path)
     def _constraint_matrices(self):
