@@ -146,13 +146,19 @@ def main():
     finite_kept = bool(torch.isfinite(fleet.state[:, kept]).all())
 
     # final gather of the sampled trajectories to rank 0 (north_star: the only collective)
-    gather_ms = None
+    gather_ms, gather_err = None, None
     if world > 1:
-        barrier()
-        g0 = time.perf_counter()
-        gather_rows(plan.traj, dst=0)
-        barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        try:
+            barrier()
+            g0 = time.perf_counter()
+            gathered, counts = gather_rows(plan.traj, dst=0)
+            barrier()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            if rank == 0 and (sum(counts) != gathered.shape[0] or not bool((gathered[:plan.total_rows] == plan.traj).all())):
+                gather_err = "gathered rows do not match"
+            del gathered
+        except Exception as exc:                      # the timed result above must survive a collective problem
+            gather_err = f"{type(exc).__name__}: {exc}"
 
     if rank != 0:
         if world > 1:
@@ -201,6 +207,9 @@ def main():
     }
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
+        out["gather_GBps_into_root"] = (world - 1) * plan.total_rows * 88 / (gather_ms * 1e-3) / 1e9
+    if gather_err is not None:
+        out["gather_error"] = gather_err
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
