@@ -1,0 +1,31 @@
+"""Time the other BASELINE.json configurations on one GPU (plan + rollout), for DESIGN.md."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
+import numpy as np, torch
+from bench import missions
+from uav_ac.fleet import Engine
+LAB_AABBS = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0],
+                      [13.3, 14.7, 6.3, 7.7, -6.0, 0.0], [20.2, 20.8, 4.0, 10.0, -3.3, -2.7]])
+eng = Engine("cuda:0")
+def t(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+for name, B, m, K, aabb in (("config2", 4096, 8, 10000, None), ("config3", 65536, 12, 10000, None),
+                            ("config4/8", 32768, 8, 5000, None), ("config5", 65536, 20, 10000, LAB_AABBS)):
+    plan = eng.plan(missions(B, m, 0, B), 3.0, 0.01)
+    fleet = eng.fleet(plan)
+    log = torch.empty((1000, 13, B), dtype=torch.float64, device="cuda:0")
+    tp = t(lambda: (eng.solve(plan), eng.sample(plan)))
+    def roll():
+        fleet.reset()
+        for _ in range(K // 1000): fleet.rollout(1000, state_log=log, aabbs=aabb)
+    tr = t(roll)
+    print(json.dumps({"config": name, "B": B, "m": m, "ticks": K, "rows": plan.total_rows, "plan_ms": tp, "rollout_ms": tr,
+                      "steps_per_s": B * K / (tr * 1e-3), "segments_per_s": B * m / (tp * 1e-3),
+                      "collided": int(fleet.collided.sum()) if aabb is not None else None}))
+    del plan, fleet, log
