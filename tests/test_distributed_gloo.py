@@ -36,19 +36,22 @@ def _worker(rank, world, port, out_dir):
     # an empty shard must not dead-lock the gather
     empty = torch.zeros((0 if rank == 1 else 3, 11), dtype=torch.float64)
     g2, c2 = gather_rows(empty, dst=0)
-    assert c2 == [3, 0]
+    assert c2 == [0 if r == 1 else 3 for r in range(world)]
+    if rank == 0:
+        assert g2.shape[0] == 3 * (world - 1)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ragged_gather_to_root_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_ragged_gather_to_root(tmp_path, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     from oracle.minsnap_oracle import plan, synthetic_missions
     ref = np.vstack([plan(w, 3.0, 0.01, method="solve") for w in synthetic_missions(5, 2)])
     got = np.load(tmp_path / "gathered.npy")
     counts = np.load(tmp_path / "counts.npy")
-    assert counts.sum() == len(ref) and len(counts) == 2
+    assert counts.sum() == len(ref) and len(counts) == world
     assert np.array_equal(got, ref)                      # mission order preserved: rank blocks are contiguous

@@ -351,15 +351,18 @@ def gather_rows(rows, dst: int = 0, group=None):
     counts = [int(c.item()) for c in counts]
     if world == 1:
         return rows, counts
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     if rank == dst:
         out = torch.empty((sum(counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         offs = np.concatenate([[0], np.cumsum(counts)])
         out[offs[dst]:offs[dst + 1]].copy_(rows)
-        reqs = [dist.irecv(out[offs[r]:offs[r + 1]], src=dist.get_global_rank(group, r) if group else r, group=group)
-                for r in range(world) if r != dst and counts[r] > 0]
-        for q in reqs:
+        # one grouped launch: under RCCL the receives run concurrently, one per direct xGMI link into the root
+        ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], peer(r), group)
+               for r in range(world) if r != dst and counts[r] > 0]
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         return out, counts
     if counts[rank] > 0:
-        dist.isend(rows.contiguous(), dst=dist.get_global_rank(group, dst) if group else dst, group=group).wait()
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, rows.contiguous(), peer(dst), group)]):
+            q.wait()
     return None, counts
