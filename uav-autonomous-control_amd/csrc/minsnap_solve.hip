@@ -1,4 +1,7 @@
-// Minimum-snap time allocation, row counting and the joint coefficient solve (gfx950).
+// Minimum-snap time allocation, row counting and the PIVOTED (banded LU) form of the coefficient solve
+// (gfx950).  The solver the API uses by default is the lane-per-mission block-Thomas recurrence of
+// minsnap_solve_bt.hip; the wave-per-mission kernel below is kept as an independent cross-check
+// (uavac_minsnap_solve_banded_dev) and documents the formulation both share.
 //
 // Replaces uav_ac/planning/minimum_snap.py (upstream paths):
 //   _generate_time_per_spline            :311-321   -> row_counts_kernel

@@ -115,8 +115,12 @@ class Context:
             raise UavacError(rc, "uavac_create failed: no usable MI355X / HIP runtime (there is no CPU fallback)")
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().uavac_destroy(self._h)
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and _lib is not None:      # at interpreter shutdown the module may be gone
+            try:
+                _lib.uavac_destroy(h)
+            except Exception:                                    # pragma: no cover
+                pass
             self._h = _P()
 
     __del__ = close
