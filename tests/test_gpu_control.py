@@ -350,3 +350,50 @@ def test_full_size_rollout_properties_config2(eng):
     assert np.abs(np.linalg.norm(X[3:7, kept], axis=0) - 1).max() < 1e-12
     nrows = (plan.row_offsets[1:] - plan.row_offsets[:-1]).cpu().numpy()
     assert np.array_equal(fleet.trajectory_index.cpu().numpy(), nrows - 1)
+
+
+def test_full_size_configs_3_and_5(eng):
+    """BASELINE configs 3 (B = 65 536, m = 12) and 5 (m = 20 + the four lab AABBs checked every tick) at full
+    batch: size-independent properties -- spot lanes against the C oracle, the sticky collision flag against a
+    recomputation from the logged positions, split-launch invariance of a checksum over the whole log."""
+    import torch
+    from oracle import c_oracle as cc
+    from oracle import minsnap_oracle as mo
+    aabbs = load_golden("fixed_missions.npz")["lab_aabbs"]
+    B = 65536
+    for m, use_aabb in ((12, False), (20, True)):
+        wps = mo.synthetic_missions(B, m)
+        plan = eng.plan(wps, 3.0, 0.01)
+        eng.check(plan)
+        assert plan.total_rows == int(plan.seg_rows.sum())
+        ab = aabbs if use_aabb else None
+        K = 600
+        a = eng.fleet(plan)
+        log, _ = a.rollout(K, state_log=True, aabbs=ab)
+        assert bool(torch.isfinite(log).all())
+        for b in (0, 32767, 65535):
+            traj = plan.mission(b)
+            state, istate = cc.initial_state(traj[0, 0:3])
+            s_ref, _ = cc.rollout(traj, state, istate, K, log_cmd=False, aabbs=ab)
+            assert col_err(log[:, :, b].cpu().numpy(), s_ref) < TOL
+            assert int(a.collided[b]) == istate[2] and int(a.trajectory_index[b]) == istate[0]
+        if use_aabb:
+            c = torch.as_tensor(aabbs, device=log.device)
+            inside = torch.zeros((K, B), dtype=torch.bool, device=log.device)
+            for o in range(len(aabbs)):
+                inside |= ((log[:, 0] >= c[o, 0]) & (log[:, 0] <= c[o, 1]) & (log[:, 1] >= c[o, 2]) & (log[:, 1] <= c[o, 3]) &
+                           (log[:, 2] >= c[o, 4]) & (log[:, 2] <= c[o, 5]))
+            assert bool((a.collided.bool() == inside.any(dim=0)).all())
+            assert 0 < int(a.collided.sum()) < B
+        total = log.sum(dim=(1, 2))                      # one checksum per tick
+        del log
+        b2 = eng.fleet(plan)
+        l1, _ = b2.rollout(250, state_log=True, aabbs=ab)
+        part = [l1.sum(dim=(1, 2))]
+        del l1
+        l2, _ = b2.rollout(K - 250, state_log=True, aabbs=ab)
+        part.append(l2.sum(dim=(1, 2)))
+        del l2
+        assert bool((torch.cat(part) == total).all())    # bit-identical logs => identical checksums
+        assert bool((a.state == b2.state).all()) and bool((a.istate == b2.istate).all())
+        del plan, a, b2

@@ -334,3 +334,23 @@ def test_batched_obstacle_replan_matches_reference_and_oracle(eng):
     fleet = eng.fleet(rp)
     fleet.rollout(500)
     assert bool((fleet.trajectory_index == 50).all())
+
+
+def test_randomised_shapes_velocities_and_steps(eng):
+    """40 random (B, m, leg lengths, velocity, dt) draws against the oracle's exact KKT path: row counts and
+    spline ids exact, samples <= 1e-7."""
+    from oracle import minsnap_oracle as mo
+    rng = np.random.default_rng(2026)
+    for _ in range(40):
+        B, m = int(rng.integers(1, 6)), int(rng.integers(1, 11))
+        lo = float(rng.uniform(0.8, 3.0)); hi = lo + float(rng.uniform(0.2, 3.0))
+        vel, dt = float(rng.uniform(0.5, 4.0)), float(rng.choice([0.005, 0.01, 0.02, 0.013]))
+        wps = mo.synthetic_missions(B, m, lo, hi) + rng.normal(0, 0.3, (B, m + 1, 3))
+        plan = eng.plan(wps, vel, dt)
+        eng.check(plan)
+        for b in range(B):
+            ref = mo.plan(wps[b], vel, dt, method="solve")
+            got = plan.mission(b)
+            assert got.shape == ref.shape, (B, m, vel, dt)
+            assert np.array_equal(got[:, 10], ref[:, 10])
+            assert col_err(got, ref) < 1e-7, (B, m, lo, hi, vel, dt)
