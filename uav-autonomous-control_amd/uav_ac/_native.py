@@ -87,7 +87,13 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise UavacError(EHIP, f"{LIB_PATH} not built: run `make -C {os.path.dirname(os.path.dirname(LIB_PATH))}`")
+            # not a fallback: build the HIP library from source (hipcc cross-compiles for gfx950), or fail loudly
+            pkg = os.path.dirname(os.path.dirname(LIB_PATH))
+            import subprocess
+            try:
+                subprocess.run(["make", "-C", pkg, "-j4"], check=True, capture_output=True)
+            except Exception as exc:
+                raise UavacError(EHIP, f"{LIB_PATH} not built and `make -C {pkg}` failed: {exc}") from exc
         try:                                   # share torch's HIP runtime when torch is in the process
             import torch  # noqa: F401
         except Exception:                      # pragma: no cover - torch is plumbing, not a requirement of the ABI
