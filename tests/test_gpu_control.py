@@ -397,3 +397,30 @@ def test_full_size_configs_3_and_5(eng):
         assert bool((torch.cat(part) == total).all())    # bit-identical logs => identical checksums
         assert bool((a.state == b2.state).all()) and bool((a.istate == b2.istate).all())
         del plan, a, b2
+
+
+def test_single_tick_launches_replay_from_a_hip_graph(eng):
+    """The device-pointer entry points only enqueue (no allocation, no sync), so a loop of single-tick launches
+    can be captured once and replayed as a HIP graph; the replay is bit-identical to eager and fused execution."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    plan = eng.plan(mo.synthetic_missions(300, 8), 3.0, 0.01)
+    eager, graphed, fused = eng.fleet(plan), eng.fleet(plan), eng.fleet(plan)
+    for _ in range(60):
+        eager.step()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graphed.step(); torch.cuda.synchronize(); graphed.reset(); torch.cuda.synchronize()     # warm the path
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(20):
+                graphed.step()
+    torch.cuda.synchronize()
+    graphed.reset()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        g.replay()
+    fused.rollout(60)
+    torch.cuda.synchronize()
+    assert bool((eager.state == graphed.state).all()) and bool((eager.istate == graphed.istate).all())
+    assert bool((eager.state == fused.state).all()) and bool((eager.istate == fused.istate).all())
