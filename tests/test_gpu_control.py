@@ -424,3 +424,28 @@ def test_single_tick_launches_replay_from_a_hip_graph(eng):
     torch.cuda.synchronize()
     assert bool((eager.state == graphed.state).all()) and bool((eager.istate == graphed.istate).all())
     assert bool((eager.state == fused.state).all()) and bool((eager.istate == fused.istate).all())
+
+
+@pytest.mark.parametrize("F", [1, 3, 10, 25])
+def test_outer_loop_every_F_ticks_and_cmd_log_only(eng, nat, F):
+    """`inner_loop_frequency` other than 10 (outer loop every tick, every 3rd, every 25th), command log alone:
+    scheduling and row cursor against the C oracle."""
+    from oracle import c_oracle as cc
+    from oracle import minsnap_oracle as mo
+    plan = eng.plan(mo.synthetic_missions(70, 8), 3.0, 0.01 if F == 10 else 0.001 * F)
+    V = nat.Vehicle.default()
+    V.inner_per_outer = F
+    V.dt_outer = V.dt * F
+    fleet = eng.fleet(plan, vehicle=V)
+    K = 400
+    _, clog = fleet.rollout(K, cmd_log=True)
+    Vc = cc.Vehicle.default()
+    Vc.inner_per_outer = F
+    Vc.dt_outer = Vc.dt * F
+    for b in (0, 33, 69):
+        traj = plan.mission(b)
+        state, istate = cc.initial_state(traj[0, 0:3], Vc)
+        _, c_ref = cc.rollout(traj, state, istate, K, Vc, log_state=False)
+        assert col_err(clog[:, :, b].cpu().numpy(), c_ref) < TOL
+        assert int(fleet.trajectory_index[b]) == istate[0] == min((K + F - 1) // F, len(traj) - 1)
+        assert col_err(fleet.state[:, b].cpu().numpy()[None], state[None]) < TOL
