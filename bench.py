@@ -49,11 +49,35 @@ def missions(B_total, m, lo, hi):
     return np.concatenate([w0, w0 + np.cumsum(L * d, axis=1)], axis=1)[lo:hi]
 
 
-def cpu_baseline():
-    """The CPU oracle (test infrastructure; here only as the timed baseline, never as product) on a
-    bounded sample of the same workload: plan + TICKS control ticks for a few missions."""
+def cpu_baseline(eng=None, wps=None):
+    """The CPU oracle (test infrastructure; here only as the timed baseline and as the checker, never as
+    product) on a bounded sample of the same workload: plan + TICKS control ticks for a few missions.  When an
+    engine is passed, the first missions of the bench batch are also planned and flown on the GPU and compared
+    with the oracle (SURVEY.md 8(c) metric): the worst relative error goes into the record."""
     from oracle import cpu_baseline as cb
-    return cb.run(segments=SEGMENTS, ticks=TICKS, velocity=VELOCITY, dt=DT)
+    out = cb.run(segments=SEGMENTS, ticks=TICKS, velocity=VELOCITY, dt=DT)
+    if eng is not None:
+        from oracle import c_oracle as co
+        n, K = 8, 3000
+        plan = eng.plan(wps[:n], VELOCITY, DT)
+        fleet = eng.fleet(plan)
+        slog, _ = fleet.rollout(K, state_log=True)
+        slog = slog.cpu().numpy()
+
+        def err(a, b):
+            return float(np.max(np.max(np.abs(a - b), axis=0) / np.maximum(1.0, np.max(np.abs(b), axis=0))))
+        e_plan = e_ctl = 0.0
+        for b in range(n):
+            traj, _, _ = co.plan(wps[b], VELOCITY, DT)
+            got = plan.mission(b)
+            assert got.shape == traj.shape
+            e_plan = max(e_plan, err(got, traj))
+            state, istate = co.initial_state(traj[0, 0:3])
+            s_ref, _ = co.rollout(traj, state, istate, K, log_cmd=False)
+            e_ctl = max(e_ctl, err(slog[:, :, b], s_ref))
+        out["max_rel_err_vs_oracle"] = {"trajectory_rows": e_plan, "state_log": e_ctl, "missions": n, "ticks": K,
+                                        "tolerance": 1e-5}
+    return out
 
 
 def main():
@@ -211,7 +235,7 @@ def main():
     if gather_err is not None:
         out["gather_error"] = gather_err
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(eng, wps)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
