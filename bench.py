@@ -36,6 +36,11 @@ SEGMENTS = 12
 TICKS = 10000
 CHUNK = 1000
 VELOCITY, DT, F = 3.0, 0.01, 10
+# fp64 VALU instructions one lane executes per tick in control_rollout_kernel<1,true,false,false>, counted in the
+# gfx950 ISA of the small-angle path every tick takes (207 in the per-tick body + 377 in the outer block / F);
+# priced against the vector fp64 peak of MI355X_MICROARCH.md (78.6 TFLOP/s = 39.3 T lane-FMA/s).
+FP64_VALU_PER_TICK = 245
+FP64_LANE_INSTR_PEAK = 39.3e12
 
 
 def missions(B_total, m, lo, hi):
@@ -219,7 +224,11 @@ def main():
                    "parallelism": f"missions sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "kernel": "control_rollout_kernel<1, true, false, false>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": roll_bytes, "avg_launch_ms": roll_avg_s * 1e3},
+                     "algorithmic_bytes_per_launch": roll_bytes, "avg_launch_ms": roll_avg_s * 1e3,
+                     "fp64_valu": {"lane_instr_per_tick": FP64_VALU_PER_TICK,
+                                   "achieved": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s,
+                                   "peak": FP64_LANE_INSTR_PEAK, "unit": "fp64 lane-instr/s",
+                                   "frac": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s / FP64_LANE_INSTR_PEAK}},
         "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
                     "ms_solve_plus_sample": plan_avg_s * 1e3,
                     "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,

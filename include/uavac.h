@@ -147,7 +147,9 @@ int uavac_state_init_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *p
 /* K ticks fused in one launch.  state_log [K][13][B] (X after every tick) or NULL;
  * cmd_log [K][12][B] (thrust_cmd, pqr_cmd, omega_command, omega after the controller part
  * of every tick) or NULL; aabbs [n_obs][6] = xmin xmax ymin ymax zmin zmax (inclusive test of
- * minimum_snap.py:327-357, evaluated on the position after every tick) or NULL. */
+ * minimum_snap.py:327-357, evaluated on the position after every tick) or NULL.
+ * Any B is accepted; the logs stream at full rate when B is a multiple of 16 (rows of B doubles
+ * then start on 128-byte lines). */
 int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
                               const int64_t *row_offsets, double *state, int32_t *istate, int B,
                               int K, double *state_log, double *cmd_log, const double *aabbs,

@@ -321,7 +321,11 @@ int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, cons
                          int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,
                          int n_obs) {
     // One compute wave + one store wave per workgroup.  (Four compute waves sharing one store wave were
-    // measured 15 % slower at B = 65 536: a single wave cannot issue a CU's 52 stores per tick fast enough.)
+    // measured 15 % slower at B = 65 536: a single wave cannot issue a CU's 52 stores per tick fast enough.
+    // Two compute waves with the store wave moving 16 B per lane -- 13 x 1 KB wave stores per tick instead of
+    // 26 x 512 B -- were 17 % slower too, 1.47 vs 1.25 ms on the same box: the per-tick barrier then couples
+    // two compute waves.)  The log rows want B to be a multiple of 16 (128-B lines): B = 65 534 runs at half
+    // the rate of B = 65 536 because every 512-B wave store then straddles two partially written lines.
     launch_cw<1>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
