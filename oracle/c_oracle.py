@@ -54,6 +54,12 @@ def lib():
         _lib.oracle_sample.argtypes = [_P, _P, C.c_int, C.c_double, _P]
         _lib.oracle_rollout.restype = None
         _lib.oracle_rollout.argtypes = [C.POINTER(Vehicle), _P, C.c_int64, _P, _P, C.c_int, _P, _P, _P, C.c_int]
+        _lib.oracle_segment_intersects_cuboid.restype = C.c_int
+        _lib.oracle_segment_intersects_cuboid.argtypes = [_P, _P, _P]
+        _lib.oracle_rrt_distances.restype = None
+        _lib.oracle_rrt_distances.argtypes = [_P, C.c_int, _P, _P]
+        _lib.oracle_rrt_star.restype = C.c_int
+        _lib.oracle_rrt_star.argtypes = [_P, _P, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 10
     return _lib
 
 
@@ -96,3 +102,41 @@ def rollout(traj, state, istate, K: int, V: Vehicle | None = None, log_state=Tru
     lib().oracle_rollout(C.byref(V), _p(traj), len(traj), _p(state), _p(istate), K, _p(slog), _p(clog), _p(ab),
                          0 if ab is None else len(ab))
     return slog, clog
+
+
+# ---------------------------------------------------------------------------------------- RRT* (rrt_oracle.c)
+RRT_STATUS = {0: "ok", 1: "no path found", 2: "cost increased after rewiring", 3: "KeyError"}
+
+
+def segment_intersects_cuboid(n1, n2, cuboid) -> bool:
+    a, b, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (n1, n2, cuboid))
+    return bool(lib().oracle_segment_intersects_cuboid(_p(a), _p(b), _p(c)))
+
+
+def rrt_distances(nodes, query):
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64).reshape(-1, 3)
+    q = np.ascontiguousarray(query, dtype=np.float64)
+    out = np.empty(len(nodes))
+    lib().oracle_rrt_distances(_p(nodes), len(nodes), _p(q), _p(out))
+    return out
+
+
+def rrt_star(start, goal, step: float, samples, cuboids=None):
+    """One RRT* run on the node sequence `samples` (max_iter, 3) that _generate_random_node returned.
+    -> dict(status, iters, nodes (n,3), canon (n,), parent (n,), best_n, best_parent, best_path (len,3), best_cost)."""
+    samples = np.ascontiguousarray(samples, dtype=np.float64).reshape(-1, 3)
+    max_iter = len(samples)
+    cap = max_iter + 1
+    start = np.ascontiguousarray(start, dtype=np.float64)
+    goal = np.ascontiguousarray(goal, dtype=np.float64)
+    cub = None if cuboids is None else np.ascontiguousarray(cuboids, dtype=np.float64).reshape(-1, 6)
+    n_obs = 0 if cub is None else len(cub)
+    nodes = np.zeros((cap, 3)); path = np.zeros((cap, 3))
+    canon = np.zeros(cap, np.int32); parent = np.zeros(cap, np.int32); bparent = np.zeros(cap, np.int32)
+    n = C.c_int(); bn = C.c_int(); blen = C.c_int(); iters = C.c_int(); bcost = C.c_double()
+    st = lib().oracle_rrt_star(_p(start), _p(goal), float(step), max_iter, _p(samples), _p(cub), n_obs,
+                               C.addressof(n), _p(nodes), _p(canon), _p(parent), C.addressof(bn), _p(bparent),
+                               C.addressof(blen), _p(path), C.addressof(bcost), C.addressof(iters))
+    return {"status": st, "iters": iters.value, "nodes": nodes[:n.value].copy(), "canon": canon[:n.value].copy(),
+            "parent": parent[:n.value].copy(), "best_n": bn.value, "best_parent": bparent[:n.value].copy(),
+            "best_path": path[:blen.value].copy(), "best_cost": bcost.value}

@@ -1,0 +1,74 @@
+"""The C oracle of the RRT* planner (oracle/rrt_oracle.c) against the golden vectors made by importing the
+reference (tests/golden/make_golden_rrt.py): uav_ac/planning/rrt.py run() on recorded node sequences."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RUNS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "rrt_*_[0-9]*.npz")))
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def padded_samples(g):
+    s = np.zeros((int(g["max_iter"]), 3))
+    s[:len(g["samples"])] = g["samples"]
+    return s
+
+
+def parents_as_coordinates(nodes, canon, parent):
+    p = parent[canon]
+    return np.where(p[:, None] >= 0, nodes[np.maximum(p, 0)], np.nan)
+
+
+def test_goldens_present():
+    assert len(RUNS) >= 10
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_rrt_star_matches_reference_run(name):
+    g = load(name)
+    obstacles = g["obstacles"] if len(g["obstacles"]) else None
+    res = co.rrt_star(g["start"], g["goal"], float(g["step"]), padded_samples(g), obstacles)
+    assert res["iters"] == len(g["samples"])                       # same early stop
+    assert np.array_equal(res["nodes"], g["all_nodes"])            # all_nodes, bit for bit, in order
+    assert np.array_equal(parents_as_coordinates(res["nodes"], res["canon"], res["parent"]), g["tree_parent"],
+                          equal_nan=True)                           # the dict `tree`
+    if str(g["error"]):
+        assert res["status"] == 1                                   # the reference raised: no path
+        return
+    assert res["status"] == 0
+    n = res["best_n"]
+    best = parents_as_coordinates(res["nodes"], res["canon"], res["best_parent"])
+    assert np.array_equal(best[:n], g["best_tree_parent"][:n], equal_nan=True)      # `best_tree`
+    assert np.all(np.isnan(g["best_tree_parent"][n:]) | (best[n:] == g["best_tree_parent"][n:]))
+    assert np.array_equal(res["best_path"], g["best_path"])
+    assert res["best_cost"] == float(g["best_cost"])
+
+
+def test_slab_test_known_answers():
+    g = load("rrt_slab")
+    got = np.array([co.segment_intersects_cuboid(a, b, c) for a, b, c in zip(g["a"], g["b"], g["cuboid"])])
+    assert np.array_equal(got, g["hit"])
+    # upstream tests/unit/planning/test_rrt.py:203-225
+    assert co.segment_intersects_cuboid([0, 0, 0], [10, 0, 0], [4.999, 5.001, -10, 10, -10, 10])
+    assert not co.segment_intersects_cuboid([0, 0, 0], [10, 0, 0], [4, 6, 1, 2, -10, 10])
+
+
+def test_distance_is_numpy_norm_here():
+    """np.linalg.norm of a 3-vector on this host's BLAS == the oracle's fma sequence (it was when the goldens were
+    made; a host whose ddot does not fuse would differ in the last bit on some inputs -- then skip)."""
+    rng = np.random.default_rng(3)
+    pts = np.round(rng.uniform(-20, 20, (5000, 3)), 2)
+    q = np.round(rng.uniform(-20, 20, 3), 2)
+    ref = np.array([np.linalg.norm(q - p) for p in pts])
+    got = co.rrt_distances(pts, q)
+    if not np.array_equal(got, ref):
+        assert np.max(np.abs(got - ref) / ref) < 4e-16
+        pytest.skip("this host's BLAS sums the 3-vector without fma")
