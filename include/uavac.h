@@ -209,6 +209,59 @@ int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, i
 int uavac_probe_outer(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out);
 int uavac_probe_inner(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out);
 
+/* ---------------------------------------------------------------------------------------------
+ * RRT* planner -- replaces uav_ac/planning/rrt.py.
+ *
+ * B independent planning problems, one wavefront each, all sharing step (= max_distance),
+ * max_iter and the obstacle list.  Random numbers stay on the host: samples[B][max_iter][3] holds,
+ * per iteration, the node RRTStar._generate_random_node (rrt.py:118-127) returned (NumPy's legacy
+ * global generator, one uniform() for the goal bias then three for the coordinates).
+ * With cap = max_iter + 1, per problem:
+ *   nodes       [cap][3]  `all_nodes` in insertion order (entry 0 = round(start, 2)); rows past
+ *                          counts[0] are zero
+ *   canon       [cap]     first entry with bit-identical coordinates = the dict key of the entry
+ *   parent      [cap]     indexed by key: key of tree[key] at the end of run(), -1 = no such key
+ *   best_parent [cap]     the same for `best_tree` (stored at the last improvement)
+ *   best_path   [cap][3]  `best_path`, start -> goal, counts[4] rows
+ *   counts      [6]       n_nodes, iterations begun, status, entries when best_tree was stored,
+ *                          best_path rows, dynamic_it_counter
+ *   best_cost             path_cost(best_path) (rrt.py:84-91); +inf without a path
+ * status: UAVAC_RRT_OK, or what the reference raises -- UAVAC_RRT_NO_PATH ("No path found",
+ * rrt.py:72-73), UAVAC_RRT_COST_INCREASED (:55-56), UAVAC_RRT_KEY_ERROR (a dict lookup failed).
+ * Per-problem failures are reported in counts, not in the return value. */
+#define UAVAC_RRT_OK 0
+#define UAVAC_RRT_NO_PATH 1
+#define UAVAC_RRT_COST_INCREASED 2
+#define UAVAC_RRT_KEY_ERROR 3
+int uavac_rrt_star_dev(uavac_ctx *ctx, const double *start, const double *goal, int B, double step,
+                       int max_iter, const double *samples, const double *cuboids, int n_obs,
+                       double *nodes, int32_t *canon, int32_t *parent, int32_t *best_parent,
+                       double *best_path, int32_t *counts, double *best_cost);
+int uavac_rrt_star(uavac_ctx *ctx, const double *start, const double *goal, int B, double step,
+                   int max_iter, const double *samples, const double *cuboids, int n_obs,
+                   double *nodes, int32_t *canon, int32_t *parent, int32_t *best_parent,
+                   double *best_path, int32_t *counts, double *best_cost);
+/* E candidate edges p0[e] -> p1[e] against n_obs cuboids [xmin xmax ymin ymax zmin zmax]:
+ * hit[e] = 1 when the segment crosses any of them (RRTStar._is_valid_connection is False),
+ * slab test of RRTStar._segment_intersects_cuboid (rrt.py:231-274). */
+int uavac_rrt_segment_hits_dev(uavac_ctx *ctx, const double *p0, const double *p1, int E,
+                               const double *cuboids, int n_obs, int32_t *hit);
+int uavac_rrt_segment_hits(uavac_ctx *ctx, const double *p0, const double *p1, int E,
+                           const double *cuboids, int n_obs, int32_t *hit);
+/* out[e] = np.linalg.norm(p1[e] - p0[e]) as _find_nearest_node / _find_valid_neighbors /
+ * _cost_to_come / path_cost take it (rrt.py:84-91,129-173).  p1 is [E][3], or one point [3] for
+ * every edge when p1_is_single != 0. */
+int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p1,
+                               int p1_is_single, int E, double *out);
+int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, int p1_is_single,
+                           int E, double *out);
+/* RRTStar._adapt_random_node_position (rrt.py:140-148) for E (sample, nearest node) pairs:
+ * out[e] = sample[e] when within step of nearest[e], else the rounded point at step from it. */
+int uavac_rrt_steer_dev(uavac_ctx *ctx, const double *sample, const double *nearest, int E,
+                        double step, double *out);
+int uavac_rrt_steer(uavac_ctx *ctx, const double *sample, const double *nearest, int E, double step,
+                    double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,8 +58,12 @@ def lib():
         _lib.oracle_segment_intersects_cuboid.argtypes = [_P, _P, _P]
         _lib.oracle_rrt_distances.restype = None
         _lib.oracle_rrt_distances.argtypes = [_P, C.c_int, _P, _P]
+        _lib.oracle_rrt_edge_lengths.restype = None
+        _lib.oracle_rrt_edge_lengths.argtypes = [_P, _P, C.c_int, C.c_int, _P]
+        _lib.oracle_rrt_steer.restype = None
+        _lib.oracle_rrt_steer.argtypes = [_P, _P, C.c_double, _P]
         _lib.oracle_rrt_star.restype = C.c_int
-        _lib.oracle_rrt_star.argtypes = [_P, _P, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 10
+        _lib.oracle_rrt_star.argtypes = [_P, _P, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 11
     return _lib
 
 
@@ -121,6 +125,21 @@ def rrt_distances(nodes, query):
     return out
 
 
+def rrt_edge_lengths(p0, p1):
+    p0 = np.ascontiguousarray(p0, dtype=np.float64).reshape(-1, 3)
+    p1 = np.ascontiguousarray(p1, dtype=np.float64)
+    out = np.empty(len(p0))
+    lib().oracle_rrt_edge_lengths(_p(p0), _p(p1), int(p1.ndim == 1), len(p0), _p(out))
+    return out
+
+
+def rrt_steer(sample, nearest, step: float):
+    a, b = np.ascontiguousarray(sample, dtype=np.float64), np.ascontiguousarray(nearest, dtype=np.float64)
+    out = np.empty(3)
+    lib().oracle_rrt_steer(_p(a), _p(b), float(step), _p(out))
+    return out
+
+
 def rrt_star(start, goal, step: float, samples, cuboids=None):
     """One RRT* run on the node sequence `samples` (max_iter, 3) that _generate_random_node returned.
     -> dict(status, iters, nodes (n,3), canon (n,), parent (n,), best_n, best_parent, best_path (len,3), best_cost)."""
@@ -133,10 +152,10 @@ def rrt_star(start, goal, step: float, samples, cuboids=None):
     n_obs = 0 if cub is None else len(cub)
     nodes = np.zeros((cap, 3)); path = np.zeros((cap, 3))
     canon = np.zeros(cap, np.int32); parent = np.zeros(cap, np.int32); bparent = np.zeros(cap, np.int32)
-    n = C.c_int(); bn = C.c_int(); blen = C.c_int(); iters = C.c_int(); bcost = C.c_double()
+    n = C.c_int(); bn = C.c_int(); blen = C.c_int(); iters = C.c_int(); bcost = C.c_double(); cnt = C.c_int()
     st = lib().oracle_rrt_star(_p(start), _p(goal), float(step), max_iter, _p(samples), _p(cub), n_obs,
                                C.addressof(n), _p(nodes), _p(canon), _p(parent), C.addressof(bn), _p(bparent),
-                               C.addressof(blen), _p(path), C.addressof(bcost), C.addressof(iters))
-    return {"status": st, "iters": iters.value, "nodes": nodes[:n.value].copy(), "canon": canon[:n.value].copy(),
+                               C.addressof(blen), _p(path), C.addressof(bcost), C.addressof(iters), C.addressof(cnt))
+    return {"status": st, "iters": iters.value, "dynamic_it_counter": cnt.value, "nodes": nodes[:n.value].copy(), "canon": canon[:n.value].copy(),
             "parent": parent[:n.value].copy(), "best_n": bn.value, "best_parent": bparent[:n.value].copy(),
             "best_path": path[:blen.value].copy(), "best_cost": bcost.value}

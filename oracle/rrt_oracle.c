@@ -88,12 +88,12 @@ static int find_key(const tree_t *t, const double *x) {
  * RRTStar.__init__ + run (rrt.py:12-80).  samples [max_iter][3]; cuboids [n_obs][6]; cap = max_iter + 1.
  * Out: n_nodes, nodes [cap][3], canon [cap], parent [cap] (final tree), best_n / best_parent (the tree
  * stored at the last improvement: entries < best_n), best_path [cap][3] (start -> goal), best_len,
- * best_cost, iters (iterations begun).  Returns RRT_*.
+ * best_cost, iters (iterations begun), dynamic_it_counter.  Returns RRT_*.
  */
 int oracle_rrt_star(const double *start_in, const double *goal_in, double step, int max_iter, const double *samples,
                     const double *cuboids, int n_obs, int *n_nodes, double *nodes, int *canon, int *parent,
                     int *best_n, int *best_parent, int *best_len, double *best_path, double *best_cost,
-                    int *iters) {
+                    int *iters, int *dynamic_it_counter) {
     const int cap = max_iter + 1;
     double start[3], goal[3];
     for (int a = 0; a < 3; ++a) { start[a] = round2(start_in[a]); goal[a] = round2(goal_in[a]); }
@@ -194,6 +194,7 @@ int oracle_rrt_star(const double *start_in, const double *goal_in, double step, 
         }
     }
     *iters = it;
+    *dynamic_it_counter = counter;
     *n_nodes = t.n;
     if (status == RRT_OK && !have_best) status = RRT_NO_PATH;
     if (status == RRT_OK) {
@@ -221,4 +222,19 @@ int oracle_rrt_star(const double *start_in, const double *goal_in, double step, 
 /* distances of `n` nodes to a query point, the way _find_nearest_node / _find_valid_neighbors take them */
 void oracle_rrt_distances(const double *nodes, int n, const double *q, double *out) {
     for (int e = 0; e < n; ++e) out[e] = norm3(q[0] - nodes[3 * e], q[1] - nodes[3 * e + 1], q[2] - nodes[3 * e + 2]);
+}
+
+/* np.linalg.norm(p1[e] - p0[e]) for E edges (p1 one point for all when p1_single) */
+void oracle_rrt_edge_lengths(const double *p0, const double *p1, int p1_single, int n, double *out) {
+    for (int e = 0; e < n; ++e) {
+        const double *a = p0 + 3 * e, *b = p1 + (p1_single ? 0 : 3 * e);
+        out[e] = norm3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
+    }
+}
+
+/* RRTStar._adapt_random_node_position (rrt.py:140-148) */
+void oracle_rrt_steer(const double *sample, const double *nearest, double step, double *out) {
+    const double d = norm3(sample[0] - nearest[0], sample[1] - nearest[1], sample[2] - nearest[2]);
+    for (int a = 0; a < 3; ++a)
+        out[a] = d > step ? round2(nearest[a] + (sample[a] - nearest[a]) * step / d) : sample[a];
 }

@@ -89,6 +89,7 @@ def check_oracle(name, scene, rrt, samples, error):
     padded[:n_iter] = samples                                  # iterations after the early stop are never read
     res = co.rrt_star(scene["start"], scene["goal"], scene["step"], padded, scene["obstacles"])
     assert res["iters"] == n_iter, (name, res["iters"], n_iter)
+    assert res["dynamic_it_counter"] == rrt.dynamic_it_counter, name
     nodes = np.array(rrt.all_nodes, dtype=float).reshape(-1, 3)
     assert np.array_equal(res["nodes"], nodes), name
     par = tree_as_parents(rrt, rrt.tree)
@@ -120,7 +121,7 @@ def main():
                 seed=seed, limits=np.array(scene["limits"], dtype=float), start=np.array(scene["start"], dtype=float),
                 goal=np.array(scene["goal"], dtype=float), step=float(scene["step"]), max_iter=scene["max_iter"],
                 obstacles=np.zeros((0, 6)) if scene["obstacles"] is None else np.array(scene["obstacles"], dtype=float),
-                samples=samples, error=error,
+                samples=samples, error=error, dynamic_it_counter=rrt.dynamic_it_counter,
                 all_nodes=np.array(rrt.all_nodes, dtype=float).reshape(-1, 3),
                 tree_parent=tree_as_parents(rrt, rrt.tree), best_tree_parent=best_tree_par,
                 best_path=np.zeros((0, 3)) if rrt.best_path is None else rrt.best_path,

@@ -1,0 +1,243 @@
+"""RRT* on the GPU (uavac_rrt_*): bit-exact against the reference's recorded runs (tests/golden/rrt_*.npz), against
+the C oracle on seeded random problems, and the reference's own unit tests (upstream
+tests/unit/planning/test_rrt.py) replayed on the drop-in `uav_ac.planning.rrt.RRTStar`."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+RUNS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "rrt_*_[0-9]*.npz")))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def parents_as_coordinates(nodes, canon, parent):
+    p = parent[canon]
+    return np.where(p[:, None] >= 0, nodes[np.maximum(p, 0)], np.nan)
+
+
+def padded(g):
+    s = np.zeros((int(g["max_iter"]), 3))
+    s[:len(g["samples"])] = g["samples"]
+    return s
+
+
+def assert_same_as_oracle(res, b, ref):
+    n = ref["nodes"].shape[0]
+    assert res.n_nodes[b] == n
+    assert res.iterations[b] == ref["iters"]
+    assert res.status[b] == ref["status"]
+    assert res.dynamic_it_counter[b] == ref["dynamic_it_counter"]
+    assert np.array_equal(res.nodes[b, :n], ref["nodes"])
+    assert np.array_equal(res.canon[b, :n], ref["canon"])
+    assert np.array_equal(res.parent[b, :n], ref["parent"])
+    if ref["status"] == 0:
+        assert res.best_n[b] == ref["best_n"]
+        assert np.array_equal(res.best_parent[b, :n], ref["best_parent"])
+        assert np.array_equal(res.path(b), ref["best_path"])
+        assert res.best_cost[b] == ref["best_cost"]
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_run_matches_reference_recording(name):
+    """The kernel on the node sequence the reference drew == the reference's all_nodes, tree, best_tree, best_path."""
+    from uav_ac.planning.rrt import rrt_star_batch
+    g = load(name)
+    obstacles = g["obstacles"] if len(g["obstacles"]) else None
+    res = rrt_star_batch(g["start"][None], g["goal"][None], float(g["step"]), padded(g)[None], obstacles)
+    n = len(g["all_nodes"])
+    assert res.iterations[0] == len(g["samples"])
+    assert res.n_nodes[0] == n
+    assert res.dynamic_it_counter[0] == int(g["dynamic_it_counter"])
+    assert np.array_equal(res.nodes[0, :n], g["all_nodes"])
+    assert np.array_equal(parents_as_coordinates(res.nodes[0, :n], res.canon[0, :n], res.parent[0, :n]), g["tree_parent"],
+                          equal_nan=True)
+    if str(g["error"]):
+        assert res.status[0] == 1
+        assert res.best_len[0] == 0 and np.isinf(res.best_cost[0])
+        return
+    assert res.status[0] == 0
+    bn = int(res.best_n[0])
+    best = parents_as_coordinates(res.nodes[0, :n], res.canon[0, :n], res.best_parent[0, :n])
+    assert np.array_equal(best[:bn], g["best_tree_parent"][:bn], equal_nan=True)
+    assert np.array_equal(res.path(0), g["best_path"])
+    assert res.best_cost[0] == float(g["best_cost"])
+
+
+def test_facade_run_reproduces_seeded_reference_run(capsys):
+    """RRTStar(...).run() after np.random.seed(s): same all_nodes / tree / best_path as the reference with the same
+    seed, and the global generator is left where the reference leaves it."""
+    from uav_ac.planning.rrt import RRTStar
+    for name in ("rrt_lab_11", "rrt_cube_1", "rrt_fine_22"):
+        g = load(name)
+        obstacles = g["obstacles"] if len(g["obstacles"]) else None
+        rrt = RRTStar(space_limits=g["limits"], start=g["start"], goal=g["goal"], max_distance=float(g["step"]),
+                      max_iterations=int(g["max_iter"]), obstacles=obstacles)
+        np.random.seed(int(g["seed"]))
+        rrt.run()
+        assert "Best path found with cost" in capsys.readouterr().out
+        assert np.array_equal(np.array(rrt.all_nodes), g["all_nodes"])
+        assert np.array_equal(rrt.best_path, g["best_path"])
+        for e, node in enumerate(rrt.all_nodes):
+            k = RRTStar._node_key(node)
+            if np.isnan(g["tree_parent"][e, 0]):
+                assert k not in rrt.tree
+            else:
+                assert np.array_equal(rrt.tree[k], g["tree_parent"][e])
+        path, cost = rrt.get_path(rrt.best_tree)
+        assert np.array_equal(path, g["best_path"]) and cost == float(g["best_cost"])
+        # generator state: the next draws equal what follows the recorded sequence
+        after = np.random.uniform(0, 1)
+        np.random.seed(int(g["seed"]))
+        for _ in range(len(g["samples"])):
+            rrt._generate_random_node()
+        assert np.random.uniform(0, 1) == after
+    g = load("rrt_short_0")
+    rrt = RRTStar(space_limits=g["limits"], start=g["start"], goal=g["goal"], max_distance=float(g["step"]),
+                  max_iterations=int(g["max_iter"]))
+    np.random.seed(0)
+    with pytest.raises(Exception, match="No path found"):
+        rrt.run()
+
+
+@pytest.mark.parametrize("max_iter,n_obs", [(300, 0), (700, 3), (1500, 2)])
+def test_batch_matches_oracle_on_random_problems(max_iter, n_obs):
+    """B problems with their own start / goal / seeds in one launch == the C oracle, problem by problem."""
+    from oracle import c_oracle as co
+    from uav_ac.planning.rrt import draw_random_nodes, rrt_star_batch
+    rng = np.random.default_rng(100 + max_iter)
+    B = 48
+    lw, up = np.array([0.0, 0.0, -4.0]), np.array([12.0, 9.0, 0.0])
+    obstacles = None
+    if n_obs:
+        lo = rng.uniform([2, 1, -4], [9, 6, -2], (n_obs, 3))
+        size = rng.uniform([0.4, 1.5, 1.0], [1.5, 4.0, 4.0], (n_obs, 3))
+        obstacles = np.round(np.stack([lo[:, 0], lo[:, 0] + size[:, 0], lo[:, 1], lo[:, 1] + size[:, 1], lo[:, 2],
+                                       lo[:, 2] + size[:, 2]], axis=1), 2)
+    starts = rng.uniform(lw, lw + [1.5, 9, 4], (B, 3))
+    goals = rng.uniform(up - [1.5, 9, 4], up, (B, 3))
+    samples = np.stack([draw_random_nodes(np.random.RandomState(1000 + b).random_sample, lw, up, np.round(goals[b], 2),
+                                          max_iter)[0] for b in range(B)])
+    step = 0.9
+    res = rrt_star_batch(starts, goals, step, samples, obstacles)
+    found = 0
+    for b in range(B):
+        ref = co.rrt_star(starts[b], goals[b], step, samples[b], obstacles)
+        assert_same_as_oracle(res, b, ref)
+        found += ref["status"] == 0
+    assert found >= B // 2                              # the comparison is not vacuous
+    assert np.all(res.nodes[np.arange(B), 0] == np.round(starts, 2))
+    for b in range(B):                                  # rows past the end are zero
+        assert not res.nodes[b, res.n_nodes[b]:].any() and not res.best_path[b, res.best_len[b]:].any()
+
+
+def test_large_tree_takes_the_scratch_path():
+    """max_iterations too large for LDS (48 B per node > 160 KB): the same kernel on HBM scratch, same results."""
+    from oracle import c_oracle as co
+    from uav_ac.planning.rrt import draw_random_nodes, rrt_star_batch
+    max_iter = 3600
+    lw, up = np.array([0.0, 0.0, 0.0]), np.array([10.0, 10.0, 10.0])
+    starts = np.array([[0.5, 0.5, 0.5], [9.0, 1.0, 2.0]])
+    goals = np.array([[9.5, 9.5, 9.5], [1.0, 9.0, 8.0]])
+    obstacles = np.array([[4.0, 6.0, -1.0, 8.0, -1.0, 11.0]])
+    samples = np.stack([draw_random_nodes(np.random.RandomState(7 + b).random_sample, lw, up, goals[b], max_iter)[0]
+                        for b in range(2)])
+    res = rrt_star_batch(starts, goals, 0.5, samples, obstacles)
+    for b in range(2):
+        assert_same_as_oracle(res, b, co.rrt_star(starts[b], goals[b], 0.5, samples[b], obstacles))
+
+
+def test_primitives_match_known_answers():
+    from oracle import c_oracle as co
+    from uav_ac.planning import rrt as R
+    g = load("rrt_slab")
+    # each segment against its own cuboid: one call per distinct cuboid would be slow; test E edges x 1 cuboid
+    # through the any-hit entry point on a few cuboids, and the whole set against the oracle edge by edge
+    for c in range(0, 40):
+        hit = R._segment_hits(g["a"], g["b"], g["cuboid"][c])
+        ref = np.array([co.segment_intersects_cuboid(a, b, g["cuboid"][c]) for a, b in zip(g["a"], g["b"])])
+        assert np.array_equal(hit, ref)
+    own = np.array([R.RRTStar._segment_intersects_cuboid(g["a"][i], g["b"][i], g["cuboid"][i]) for i in range(300)])
+    assert np.array_equal(own, g["hit"][:300])
+    # any-hit over several cuboids
+    multi = R._segment_hits(g["a"], g["b"], g["cuboid"][:5])
+    ref = np.zeros(len(g["a"]), bool)
+    for c in range(5):
+        ref |= np.array([co.segment_intersects_cuboid(a, b, g["cuboid"][c]) for a, b in zip(g["a"], g["b"])])
+    assert np.array_equal(multi, ref)
+    # edge lengths and steering, bit for bit
+    assert np.array_equal(R._edge_lengths(g["a"], g["b"]), co.rrt_edge_lengths(g["a"], g["b"]))
+    assert np.array_equal(R._edge_lengths(g["a"], g["b"][0]), co.rrt_edge_lengths(g["a"], g["b"][0]))
+    rrt = R.RRTStar(np.array([[0, 0, 0], [10, 10, 10]]), np.array([0, 0, 0]), np.array([8, 8, 8]), 2, 1)
+    for i in range(200):
+        got = rrt._adapt_random_node_position(g["a"][i], g["b"][i])
+        assert np.array_equal(got, co.rrt_steer(g["a"][i], g["b"][i], 2.0))
+
+
+# ------------------------------------------------------------- upstream tests/unit/planning/test_rrt.py, replayed
+@pytest.fixture
+def rrt_object():
+    from uav_ac.planning.rrt import RRTStar
+    return RRTStar(space_limits=np.array([[0, 0, 0], [10, 10, 10]]), start=np.array([0, 0, 0]),
+                   goal=np.array([8, 8, 8]), max_distance=2, max_iterations=1)
+
+
+def test_reference_unit_tests_geometry(rrt_object):
+    from uav_ac.planning.rrt import RRTStar
+    assert np.isclose(RRTStar.path_cost(np.array([[1, 1, 1], [3, 3, 9], [11, 5, 5], [1, 1, 1]])), 29.1, atol=0.1)
+    rrt_object.obstacles = None
+    path = np.array([[0., 0., 0.], [2., 0., 0.], [4., 0., 0.], [6., 0., 0.]])
+    assert rrt_object.simplify_path(path) == pytest.approx(np.array([[0., 0., 0.], [6., 0., 0.]]))
+    rrt_object.obstacles = np.array([[5., 7., -1., 1., -1., 1.]])
+    path = np.array([[0., 0., 0.], [4., 2., 0.], [8., 2., 0.], [12., 0., 0.]])
+    result = rrt_object.simplify_path(path)
+    assert len(result) > 2
+    assert all(rrt_object._is_valid_connection(a, b) for a, b in zip(result[:-1], result[1:]))
+    rrt_object.obstacles = None
+    node = rrt_object._generate_random_node()
+    assert np.all(node >= rrt_object.space_limits_lw) and np.all(node <= rrt_object.space_limits_up)
+    rrt_object.all_nodes = np.array([[1, 1, 1], [3, 3, 9], [11, 5, 5], [1, 1, 1]])
+    for q in ([1, 1, 1], [3, 3, 9], [11, 5, 5]):
+        assert np.all(rrt_object._find_nearest_node(q) == q)
+    rrt_object.step_size = 2
+    assert np.all(rrt_object._adapt_random_node_position(np.array([1, 1, 1]), np.array([3, 3, 9])) ==
+                  np.array([2.53, 2.53, 7.11]))
+    rrt_object.all_nodes = np.array([[1, 1, 1], [2, 2, 2], [11, 5, 5], [1, 1, 1]])
+    rrt_object.neighborhood_radius = 3
+    assert np.all(rrt_object._find_valid_neighbors(np.array([1, 1, 1])) == np.array([[1, 1, 1], [2, 2, 2], [1, 1, 1]]))
+    rrt_object.obstacles = np.array([[4.999, 5.001, -10., 10., -10., 10.]])
+    assert not rrt_object._is_valid_connection(np.array([0., 0., 0.]), np.array([10., 0., 0.]))
+    rrt_object.obstacles = np.array([[4., 6., 1., 2., -10., 10.]])
+    assert rrt_object._is_valid_connection(np.array([0., 0., 0.]), np.array([10., 0., 0.]))
+
+
+def test_reference_unit_tests_tree_bookkeeping(rrt_object):
+    start = rrt_object.start = np.array([0., 0., 0.])
+    assert rrt_object._cost_to_come(start) == pytest.approx(0.0)
+    rrt_object.tree = {"[0.0, 0.0, 2.0]": start, "[0.0, 2.0, 2.0]": np.array([0., 0., 2.])}
+    assert rrt_object._cost_to_come(np.array([0., 2., 2.])) == pytest.approx(4.0)
+    # best neighbor: lowest cost through the tree
+    near, detour, costly = np.array([0., 0., 2.]), np.array([0., 3., 0.]), np.array([0., 0., 1.])
+    rrt_object.tree = {"[0.0, 0.0, 2.0]": start, "[0.0, 3.0, 0.0]": start, "[0.0, 0.0, 1.0]": detour}
+    assert np.all(rrt_object._find_best_neighbor([costly, near], np.array([0., 0., 3.])) == near)
+    # rewiring
+    new_node = np.array([0., 0., 1.])
+    rrt_object.tree = {"[0.0, 0.0, 5.0]": start, "[1.0, 0.0, 0.0]": np.array([0., 0., 5.]),
+                       "[0.0, 1.0, 0.0]": np.array([0., 0., 5.]), "[0.0, 0.0, 1.0]": start}
+    assert rrt_object._rewire_safely([np.array([1., 0., 0.]), np.array([0., 1., 0.])], new_node)
+    assert np.all(rrt_object.tree["[1.0, 0.0, 0.0]"] == new_node)
+    assert np.all(rrt_object.tree["[0.0, 1.0, 0.0]"] == new_node)
+    rrt_object.tree = {"[0.0, 0.0, 1.0]": start}
+    assert not rrt_object._rewire_safely([start], new_node)
+    assert "[0.0, 0.0, 0.0]" not in rrt_object.tree
+    # update keeps the cheaper parent
+    rrt_object.tree = {"[0.0, 0.0, 2.0]": start, "[0.0, 3.0, 0.0]": start}
+    rrt_object._update_tree(np.array([0., 3., 0.]), np.array([0., 0., 2.]))
+    assert np.all(rrt_object.tree["[0.0, 0.0, 2.0]"] == start)

@@ -37,6 +37,7 @@ def test_rrt_star_matches_reference_run(name):
     obstacles = g["obstacles"] if len(g["obstacles"]) else None
     res = co.rrt_star(g["start"], g["goal"], float(g["step"]), padded_samples(g), obstacles)
     assert res["iters"] == len(g["samples"])                       # same early stop
+    assert res["dynamic_it_counter"] == int(g["dynamic_it_counter"])
     assert np.array_equal(res["nodes"], g["all_nodes"])            # all_nodes, bit for bit, in order
     assert np.array_equal(parents_as_coordinates(res["nodes"], res["canon"], res["parent"]), g["tree_parent"],
                           equal_nan=True)                           # the dict `tree`
@@ -72,3 +73,22 @@ def test_distance_is_numpy_norm_here():
     if not np.array_equal(got, ref):
         assert np.max(np.abs(got - ref) / ref) < 4e-16
         pytest.skip("this host's BLAS sums the 3-vector without fma")
+
+
+# ----------------------------------------------------------------------------- host logic of the product
+def test_draw_random_nodes_reproduces_the_reference_stream():
+    """uav_ac.planning.rrt.draw_random_nodes == 2 000 calls of the reference's _generate_random_node after
+    np.random.seed (golden rrt_draws.npz), and it can leave the generator where the reference would."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "uav-autonomous-control_amd"))
+    from uav_ac.planning.rrt import draw_random_nodes
+    g = load("rrt_draws")
+    rs = np.random.RandomState(int(g["seed"]))
+    nodes, consumed = draw_random_nodes(rs.random_sample, g["limits"][0], g["limits"][1], g["goal"], len(g["nodes"]))
+    assert np.array_equal(nodes, g["nodes"])
+    assert np.all(np.diff(np.concatenate([[0], consumed])) % 3 == 1)            # 1 or 4 doubles per draw
+    rs = np.random.RandomState(int(g["seed"]))
+    rs.random_sample(int(consumed[-1]))
+    assert rs.uniform(0, 1) == float(g["next_uniform"])
+    goal_share = np.mean(np.all(nodes == g["goal"], axis=1))
+    assert 0.10 < goal_share < 0.20                                              # epsilon = 0.15

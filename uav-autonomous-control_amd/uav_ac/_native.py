@@ -77,6 +77,14 @@ _SIGNATURES = {
     "uavac_dynamics_step": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, C.c_int, _P, C.c_int]),
     "uavac_probe_outer": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
     "uavac_probe_inner": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
+    "uavac_rrt_star_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 7),
+    "uavac_rrt_star": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 7),
+    "uavac_rrt_segment_hits_dev": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P]),
+    "uavac_rrt_segment_hits": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P]),
+    "uavac_rrt_edge_lengths_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "uavac_rrt_edge_lengths": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "uavac_rrt_steer_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P]),
+    "uavac_rrt_steer": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P]),
 }
 
 _lib = None
