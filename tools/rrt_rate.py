@@ -1,0 +1,55 @@
+"""Throughput of the batched RRT* kernel (lab obstacle set, 1 000 iterations per problem) beside the scalar C
+oracle on one host core.  Device-resident inputs/outputs (torch tensors through the _dev entry point)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
+import numpy as np
+import torch
+from uav_ac import _native as nat
+from uav_ac.planning.rrt import draw_random_nodes_batch
+from oracle import c_oracle as co
+
+LAB = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0],
+                [13.3, 14.7, 6.3, 7.7, -6.0, 0.0], [20.2, 20.8, 4.0, 10.0, -3.3, -2.7]])
+lw, up = np.array([0.0, 0.0, -6.0]), np.array([24.0, 14.0, 0.0])
+max_iter = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+step = 1.5
+Bs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [256, 1024, 4096]
+Bmax = max(Bs)
+rng = np.random.default_rng(5)
+starts = np.round(rng.uniform([0.5, 1, -3], [2, 13, -1], (Bmax, 3)), 2)
+goals = np.round(rng.uniform([22, 1, -3], [23.5, 13, -1], (Bmax, 3)), 2)
+t0 = time.perf_counter()
+samples = draw_random_nodes_batch(np.arange(Bmax), lw, up, goals, max_iter)
+print(f"host: drew {Bmax} x {max_iter} nodes in {time.perf_counter() - t0:.1f} s")
+
+dev = torch.device("cuda:0")
+ctx = nat.Context(0)
+ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+P = lambda t: nat._P(t.data_ptr())
+cub = torch.as_tensor(LAB, device=dev)
+cap = max_iter + 1
+for B in Bs:
+    s = torch.as_tensor(starts[:B], device=dev); g = torch.as_tensor(goals[:B], device=dev)
+    smp = torch.as_tensor(samples[:B], device=dev)
+    nodes = torch.empty((B, cap, 3), dtype=torch.float64, device=dev); path = torch.empty_like(nodes)
+    canon = torch.empty((B, cap), dtype=torch.int32, device=dev); par = torch.empty_like(canon); bpar = torch.empty_like(canon)
+    counts = torch.empty((B, 6), dtype=torch.int32, device=dev); cost = torch.empty(B, dtype=torch.float64, device=dev)
+    def run():
+        ctx.call("uavac_rrt_star_dev", P(s), P(g), B, step, max_iter, P(smp), P(cub), len(LAB), P(nodes), P(canon), P(par),
+                 P(bpar), P(path), P(counts), P(cost))
+    run(); torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record(); run(); b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    c = counts.cpu().numpy()
+    its = int(c[:, 1].sum())
+    print(f"B={B}: {ms:.1f} ms  -> {B / ms * 1e3:.0f} problems/s, {its / ms * 1e3 / 1e6:.2f} M iterations/s; "
+          f"found {int((c[:, 2] == 0).sum())}/{B}, mean iterations {c[:, 1].mean():.0f}, mean nodes {c[:, 0].mean():.0f}")
+
+n_cpu = 24
+t0 = time.perf_counter(); its = 0
+for b in range(n_cpu):
+    its += co.rrt_star(starts[b], goals[b], step, samples[b], LAB)["iters"]
+dt = time.perf_counter() - t0
+print(f"C oracle, 1 core: {n_cpu / dt:.1f} problems/s, {its / dt / 1e6:.3f} M iterations/s")

@@ -104,12 +104,14 @@ __device__ __forceinline__ void wave_argmin(double &d, int &e) {
     }
 }
 
+template <bool USE_LDS>
 __global__ void __launch_bounds__(W)
 rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ goals, int B, double step, int max_iter,
                 const double *__restrict__ samples, const double *__restrict__ cuboids, int n_obs,
                 double *__restrict__ g_nodes, int32_t *__restrict__ g_canon, int32_t *__restrict__ g_parent,
                 int32_t *__restrict__ g_best_parent, double *__restrict__ g_best_path, int32_t *__restrict__ counts,
-                double *__restrict__ best_cost_out, double *__restrict__ scratch, int use_lds) {
+                double *__restrict__ best_cost_out, double *__restrict__ scratch) {
+    constexpr bool use_lds = USE_LDS;
     extern __shared__ double lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int cap = max_iter + 1;
@@ -443,11 +445,15 @@ int uavac_rrt_star_dev(uavac_ctx *ctx, const double *start, const double *goal, 
             ctx->ws_cap = need;
         }
     } else if (lds > 64 * 1024) {
-        UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)rrt_star_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)rrt_star_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
     }
-    hipLaunchKernelGGL(rrt_star_kernel, dim3(B), dim3(W), use_lds ? lds : 0, ctx->stream, start, goal, B, step, max_iter,
-                       samples, cuboids, n_obs, nodes, canon, parent, best_parent, best_path, counts, best_cost,
-                       ctx->d_ws, use_lds);
+    if (use_lds)
+        hipLaunchKernelGGL(rrt_star_kernel<true>, dim3(B), dim3(W), lds, ctx->stream, start, goal, B, step, max_iter, samples,
+                           cuboids, n_obs, nodes, canon, parent, best_parent, best_path, counts, best_cost, ctx->d_ws);
+    else
+        hipLaunchKernelGGL(rrt_star_kernel<false>, dim3(B), dim3(W), 0, ctx->stream, start, goal, B, step, max_iter, samples,
+                           cuboids, n_obs, nodes, canon, parent, best_parent, best_path, counts, best_cost, ctx->d_ws);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

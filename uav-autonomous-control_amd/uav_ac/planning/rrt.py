@@ -49,6 +49,29 @@ def draw_random_nodes(random_sample, limits_lw, limits_up, goal, n: int, epsilon
     return nodes, consumed
 
 
+def draw_random_nodes_batch(seeds, limits_lw, limits_up, goals, n: int, epsilon: float = EPSILON) -> np.ndarray:
+    """draw_random_nodes for B problems at once: problem b gets what the reference draws after
+    `np.random.seed(seeds[b])`.  Each stream comes from its own RandomState; the 1-or-4 stride through the streams
+    is walked for all problems together.  -> (B, n, 3)."""
+    lw = np.asarray(limits_lw, dtype=np.float64)
+    up = np.asarray(limits_up, dtype=np.float64)
+    goals = np.asarray(goals, dtype=np.float64).reshape(-1, 3)
+    B = goals.shape[0]
+    if len(seeds) != B:
+        raise ValueError("one seed per problem")
+    streams = np.stack([np.random.RandomState(int(sd)).random_sample(4 * n) for sd in seeds])
+    streams = np.concatenate([streams, np.zeros((B, 3))], axis=1)          # reads past the last used double are masked
+    rows = np.arange(B)
+    pos = np.zeros(B, dtype=np.int64)
+    nodes = np.empty((B, n, 3))
+    for i in range(n):
+        take_goal = 0.0 + (1.0 - 0.0) * streams[rows, pos] < epsilon
+        xyz = np.stack([streams[rows, pos + 1], streams[rows, pos + 2], streams[rows, pos + 3]], axis=1)
+        nodes[:, i] = np.where(take_goal[:, None], goals, np.round(lw + (up - lw) * xyz, 2))
+        pos += np.where(take_goal, 1, 4)
+    return nodes
+
+
 # ---------------------------------------------------------------------------------------------------- batched
 @dataclass
 class RRTBatch:
