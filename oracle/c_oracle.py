@@ -54,6 +54,9 @@ def lib():
         _lib.oracle_sample.argtypes = [_P, _P, C.c_int, C.c_double, _P]
         _lib.oracle_rollout.restype = None
         _lib.oracle_rollout.argtypes = [C.POINTER(Vehicle), _P, C.c_int64, _P, _P, C.c_int, _P, _P, _P, C.c_int]
+        _lib.oracle_bench_threads.restype = C.c_int64
+        _lib.oracle_bench_threads.argtypes = [C.POINTER(Vehicle), _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                              C.c_int, C.c_double, _P]
         _lib.oracle_segment_intersects_cuboid.restype = C.c_int
         _lib.oracle_segment_intersects_cuboid.argtypes = [_P, _P, _P]
         _lib.oracle_rrt_distances.restype = None
@@ -106,6 +109,17 @@ def rollout(traj, state, istate, K: int, V: Vehicle | None = None, log_state=Tru
     lib().oracle_rollout(C.byref(V), _p(traj), len(traj), _p(state), _p(istate), K, _p(slog), _p(clog), _p(ab),
                          0 if ab is None else len(ab))
     return slog, clog
+
+
+def bench_threads(wps, velocity: float, dt: float, ticks: int, n_threads: int, budget_s: float, V: Vehicle | None = None):
+    """Whole missions (plan + `ticks` control ticks with the state log) on n_threads POSIX threads for budget_s of wall
+    time, entirely inside the C library.  -> (missions completed, wall seconds)."""
+    V = V or Vehicle.default()
+    wps = np.ascontiguousarray(wps, dtype=np.float64)
+    elapsed = C.c_double()
+    done = lib().oracle_bench_threads(C.byref(V), _p(wps), wps.shape[0], wps.shape[1] - 1, float(velocity), float(dt),
+                                      int(ticks), int(n_threads), float(budget_s), C.addressof(elapsed))
+    return int(done), elapsed.value
 
 
 # ---------------------------------------------------------------------------------------- RRT* (rrt_oracle.c)

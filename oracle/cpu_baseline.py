@@ -10,31 +10,14 @@ from .minsnap_oracle import synthetic_missions
 
 
 def _all_cores(wps, V, segments, ticks, velocity, dt, budget_s):
-    """The same scalar work on every host core at once: threads (ctypes releases the GIL inside the C calls;
-    no fork from a process that holds a GPU context)."""
+    """The same scalar work on every host core at once: POSIX threads inside the C library, each planning and
+    flying whole missions with its own buffers (no Python in the loop, no fork from a process that holds a GPU
+    context)."""
     import os
-    import threading
     n_thr = os.cpu_count() or 1
-    done = [0] * n_thr
-    t_end = time.perf_counter() + budget_s
-
-    def work(i):
-        k = i
-        while time.perf_counter() < t_end:
-            traj, _, _ = co.plan(wps[k % len(wps)], velocity, dt)
-            state, istate = co.initial_state(traj[0, 0:3], V)
-            co.rollout(traj, state, istate, ticks, V, log_state=True, log_cmd=False)
-            done[i] += 1
-            k += n_thr
-    t0 = time.perf_counter()
-    threads = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    elapsed = time.perf_counter() - t0
-    return {"value": sum(done) * ticks / elapsed, "unit": "UAV control-steps/s", "cores": n_thr,
-            "sample": f"{sum(done)} missions (plan + {ticks} ticks each) on {n_thr} threads, {elapsed:.1f} s wall"}
+    done, elapsed = co.bench_threads(wps, velocity, dt, ticks, n_thr, budget_s, V)
+    return {"value": done * ticks / elapsed, "unit": "UAV control-steps/s", "cores": n_thr,
+            "sample": f"{done} missions (plan + {ticks} ticks each) on {n_thr} threads, {elapsed:.1f} s wall"}
 
 
 def run(segments: int, ticks: int, velocity: float, dt: float, budget_s: float = 12.0, max_missions: int = 100000):

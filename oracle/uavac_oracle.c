@@ -335,3 +335,67 @@ void oracle_rollout(const oracle_vehicle *V, const double *traj, int64_t nrows, 
     memcpy(state + 23, u.pqr, 3 * sizeof(double));
     istate[0] = u.idx; istate[1] = u.inner; istate[2] = u.collided;
 }
+
+/* ------------------------------------------------------------------ all-core timing leg (bench.py cpu_baseline)
+ * n_threads POSIX threads, each planning and flying whole missions (mission i of wps[n][m+1][3], i = tid,
+ * tid + n_threads, ... recycled) with its own buffers until budget_s of wall time has passed.  Returns the
+ * missions completed by all threads; *elapsed_s = wall time from start to the last thread's end. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    const oracle_vehicle *V;
+    const double *wps;
+    int n, m, ticks, tid, n_threads;
+    double velocity, dt, t_end;
+    int64_t done;
+} bench_arg;
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *bench_worker(void *p) {
+    bench_arg *a = (bench_arg *)p;
+    const int m = a->m;
+    double *coeffs = (double *)malloc(sizeof(double) * 24 * (size_t)m);
+    double *times = (double *)malloc(sizeof(double) * (size_t)m);
+    double *slog = (double *)malloc(sizeof(double) * 13 * (size_t)a->ticks);
+    double *traj = NULL;
+    int64_t cap = 0;
+    for (int64_t i = a->tid; now_s() < a->t_end; i += a->n_threads) {
+        const double *wp = a->wps + (size_t)(i % a->n) * (size_t)(m + 1) * 3;
+        if (oracle_solve(wp, m, a->velocity, coeffs, times) != 0) break;
+        const int64_t rows = oracle_row_count(times, m, a->dt);
+        if (rows > cap) { free(traj); cap = rows + rows / 4; traj = (double *)malloc(sizeof(double) * 11 * (size_t)cap); }
+        oracle_sample(coeffs, times, m, a->dt, traj);
+        double state[26] = {0};
+        int32_t istate[3] = {0, 0, 0};
+        state[0] = traj[0]; state[1] = traj[1]; state[2] = traj[2]; state[3] = 1.0;
+        const double hover = sqrt(a->V->mass * a->V->g / (4.0 * a->V->kf));
+        for (int r = 13; r < 21; ++r) state[r] = hover;
+        oracle_rollout(a->V, traj, rows, state, istate, a->ticks, slog, NULL, NULL, 0);
+        ++a->done;
+    }
+    free(coeffs); free(times); free(slog); free(traj);
+    return NULL;
+}
+
+int64_t oracle_bench_threads(const oracle_vehicle *V, const double *wps, int n, int m, double velocity, double dt,
+                             int ticks, int n_threads, double budget_s, double *elapsed_s) {
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    bench_arg *args = (bench_arg *)malloc(sizeof(bench_arg) * (size_t)n_threads);
+    const double t0 = now_s();
+    for (int t = 0; t < n_threads; ++t) {
+        bench_arg a = {V, wps, n, m, ticks, t, n_threads, velocity, dt, t0 + budget_s, 0};
+        args[t] = a;
+        pthread_create(&th[t], NULL, bench_worker, &args[t]);
+    }
+    int64_t done = 0;
+    for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); done += args[t].done; }
+    *elapsed_s = now_s() - t0;
+    free(th); free(args);
+    return done;
+}
