@@ -334,6 +334,18 @@ def test_batched_obstacle_replan_matches_reference_and_oracle(eng):
     fleet = eng.fleet(rp)
     fleet.rollout(500)
     assert bool((fleet.trajectory_index == 50).all())
+    assert rp.converged.all()
+    # an ill-posed mission (its straight leg crosses a bar squarely: midpoints never leave it) ends the strict call
+    # but only marks itself in the lenient one; the others come out as before
+    bar = np.array([[4.0, 5.0, -10.0, 10.0, -10.0, 10.0]])
+    through = np.array([[0.0, 0.0, -2.0], [9.0, 0.0, -2.0], [9.0, 5.0, -2.0]])
+    around = np.array([[0.0, 12.0, -2.0], [3.0, 14.0, -2.0], [9.0, 14.0, -2.5]])
+    with pytest.raises(RuntimeError):
+        eng.plan_collision_free([around, through], bar, 2.0, 0.01)
+    lenient = eng.plan_collision_free([around, through], bar, 2.0, 0.01, strict=False)
+    assert list(lenient.converged) == [True, False]
+    assert col_err(lenient.mission(0), mo.plan(around, 2.0, 0.01, method="solve")) < 1e-7
+    assert len(lenient.final_waypoints[1]) - 1 <= 64 and len(lenient.mission(1)) > 0
 
 
 def test_randomised_shapes_velocities_and_steps(eng):

@@ -1,0 +1,44 @@
+"""Batched obstacle-aware planning (Engine.plan_collision_free): B 8-segment missions of the 8(d)
+generator against the 4 lab cuboids, timed end to end (GPU rounds + host midpoint insertion), beside the NumPy
+oracle's loop (exact-solve path) on a sample of the same missions on one host core."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
+import numpy as np
+import torch
+from bench import missions
+from uav_ac.fleet import Engine
+from oracle import minsnap_oracle as mo
+
+LAB = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0],
+                [13.3, 14.7, 6.3, 7.7, -6.0, 0.0], [20.2, 20.8, 4.0, 10.0, -3.3, -2.7]])
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+m = 8
+wps = missions(4 * B, m, 0, 4 * B)
+# well-posed missions only: no waypoint within 0.4 m of a cuboid (the reference's loop cannot end otherwise)
+ok = np.ones(len(wps), bool)
+for c in LAB:
+    inside = ((wps[..., 0] >= c[0] - .4) & (wps[..., 0] <= c[1] + .4) & (wps[..., 1] >= c[2] - .4) & (wps[..., 1] <= c[3] + .4) &
+              (wps[..., 2] >= c[4] - .4) & (wps[..., 2] <= c[5] + .4))
+    ok &= ~inside.any(axis=1)
+wps = wps[ok][:B]
+B = len(wps)
+eng = Engine("cuda:0")
+eng.plan_collision_free(wps[:64], LAB, 3.0, 0.01, strict=False)          # warm-up
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+rp = eng.plan_collision_free(wps, LAB, 3.0, 0.01, strict=False)
+torch.cuda.synchronize()
+dt_gpu = time.perf_counter() - t0
+segs = sum(len(w) - 1 for w in rp.final_waypoints)
+grew = sum(len(w) - 1 > m for w in rp.final_waypoints)
+print(f"B={B}: {dt_gpu*1e3:.1f} ms end to end -> {B/dt_gpu:.0f} missions/s; {int((~rp.converged).sum())} ill-posed (gave up), "
+      f"{grew} missions needed midpoints, "
+      f"{segs} final segments, {rp.total_rows} rows")
+good = np.flatnonzero(rp.converged)[:12]
+n_cpu = len(good)
+t0 = time.perf_counter()
+for b in good:
+    mo.plan_collision_free(wps[b], LAB, 3.0, 0.01, method="solve")
+dt_cpu = time.perf_counter() - t0
+print(f"NumPy oracle, 1 core: {n_cpu/dt_cpu:.2f} missions/s")

@@ -67,6 +67,7 @@ class RaggedPlan:
     traj: "object"                   # (N, 11) f64
     total_rows: int
     start_positions: "object"        # (B, 3) f64
+    converged: "object" = None       # (B,) bool, host: False where the bounded obstacle loop gave up
 
     def mission(self, b: int) -> np.ndarray:
         ro = self.row_offsets[b:b + 2].cpu().numpy()
@@ -122,7 +123,7 @@ class Engine:
         return plan
 
     def plan_collision_free(self, waypoints, obstacles, velocity: float = 1.0, dt: float = 0.01,
-                            max_iterations: int = 64) -> RaggedPlan:
+                            max_iterations: int = 64, strict: bool = True) -> RaggedPlan:
         """Batched `MinimumSnap(path, obstacles, velocity, dt).get_trajectory()` with obstacles
         (minimum_snap.py:63-95) for B missions at once.
 
@@ -132,7 +133,9 @@ class Engine:
         together: each round plans every still-active mission (grouped by segment count) and the sampler itself
         reports the hit splines (`uavac_minsnap_sample_hits_dev`); only the midpoint insertion is host work.
         `waypoints`: (B, m+1, 3) array or a list of (m_b+1, 3) arrays.  The loop is bounded (the reference's is
-        not: it cannot end when a waypoint lies inside a cuboid).
+        not: it cannot end when a waypoint lies inside a cuboid, or when a leg crosses one squarely).  A mission
+        that exhausts `max_iterations` or UAVAC_MAX_SEGMENTS raises RuntimeError when `strict`; otherwise it is
+        reported in `RaggedPlan.converged` (False) with its last (still colliding) trajectory and the batch goes on.
         """
         torch = self._torch
         wps = [np.ascontiguousarray(w, dtype=np.float64) for w in waypoints]
@@ -141,6 +144,7 @@ class Engine:
             raise ValueError("waypoints must be B arrays of shape (m+1, 3)")
         cuboids = np.zeros((0, 6)) if obstacles is None else np.asarray(obstacles, dtype=np.float64).reshape(-1, 6)
         source = [None] * B                                    # mission -> (group Plan, index inside it)
+        failed = set()
 
         def run_round(ids, cub):
             groups = {}
@@ -149,7 +153,10 @@ class Engine:
             again = []
             for m, members in sorted(groups.items()):
                 if m > nat.MAX_SEGMENTS:
-                    raise RuntimeError(f"obstacle correction needs more than {nat.MAX_SEGMENTS} splines")
+                    if strict:
+                        raise RuntimeError(f"obstacle correction needs more than {nat.MAX_SEGMENTS} splines")
+                    failed.update(members)                            # keeps the plan of the previous round
+                    continue
                 plan, hit = self._plan_group(np.stack([wps[b] for b in members]), velocity, dt, cub)
                 for j, b in enumerate(members):
                     source[b] = (plan, j)
@@ -158,6 +165,9 @@ class Engine:
                     for j in np.flatnonzero(hit.any(axis=1)):
                         b = members[j]
                         idx = np.flatnonzero(hit[j]) + 1              # spline s -> insert before waypoint s+1
+                        if m + len(idx) > nat.MAX_SEGMENTS and not strict:
+                            failed.add(b)                             # would outgrow the kernels: stop here
+                            continue
                         mids = (wps[b][idx - 1] + wps[b][idx]) / 2
                         wps[b] = np.insert(wps[b], idx, mids, axis=0)
                         again.append(b)
@@ -166,13 +176,15 @@ class Engine:
         if len(cuboids) == 0:
             run_round(list(range(B)), None)
         for cub in cuboids:
-            active = list(range(B))
+            active = [b for b in range(B) if b not in failed]
             for _ in range(max_iterations + 1):
                 if not active:
                     break
                 active = run_round(active, cub)
             else:
-                raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
+                if strict:
+                    raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
+                failed.update(active)
 
         # stitch the final trajectories together in mission order
         nrows = torch.zeros((B,), dtype=torch.int64, device=self.device)
@@ -197,7 +209,9 @@ class Engine:
             within = torch.arange(int(length.sum().item()), device=self.device) - (torch.cumsum(length, 0) - length)[rep]
             traj[offsets[ids_t][rep] + within] = plan.traj[plan.row_offsets[js_t][rep] + within]
         starts = torch.as_tensor(np.stack([w[0] for w in wps]), dtype=torch.float64, device=self.device)
-        return RaggedPlan(B, float(velocity), float(dt), wps, offsets, traj, total, starts)
+        converged = np.ones(B, dtype=bool)
+        converged[sorted(failed)] = False
+        return RaggedPlan(B, float(velocity), float(dt), wps, offsets, traj, total, starts, converged)
 
     def _plan_group(self, wp_host, velocity, dt, cuboid):
         """Plan one group of equal-m missions; with a cuboid also return the (B, m) hit flags."""
