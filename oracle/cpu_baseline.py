@@ -9,15 +9,41 @@ from . import c_oracle as co
 from .minsnap_oracle import synthetic_missions
 
 
-def _all_cores(wps, V, segments, ticks, velocity, dt, budget_s):
-    """The same scalar work on every host core at once: POSIX threads inside the C library, each planning and
-    flying whole missions with its own buffers (no Python in the loop, no fork from a process that holds a GPU
-    context)."""
+def effective_cpus():
+    """CPUs this process may really use: scheduler affinity, capped by the cgroup CPU quota (a container can see
+    256 CPUs and own 8 of them).  -> (n, description)."""
+    import math
     import os
-    n_thr = os.cpu_count() or 1
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"os.cpu_count()={os.cpu_count()}, affinity={n}"
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2
+            q, period = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except OSError:
+        try:                                                             # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / period
+        except OSError:
+            pass
+    if quota is not None:
+        note += f", cgroup quota={quota:g} CPUs"
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n, note
+
+
+def _all_cores(wps, V, segments, ticks, velocity, dt, budget_s):
+    """The same scalar work on every CPU this process owns at once: POSIX threads inside the C library, each
+    planning and flying whole missions with its own buffers (no Python in the loop, no fork from a process that
+    holds a GPU context)."""
+    n_thr, note = effective_cpus()
     done, elapsed = co.bench_threads(wps, velocity, dt, ticks, n_thr, budget_s, V)
     return {"value": done * ticks / elapsed, "unit": "UAV control-steps/s", "cores": n_thr,
-            "sample": f"{done} missions (plan + {ticks} ticks each) on {n_thr} threads, {elapsed:.1f} s wall"}
+            "sample": f"{done} missions (plan + {ticks} ticks each) on {n_thr} threads, {elapsed:.1f} s wall ({note})"}
 
 
 def run(segments: int, ticks: int, velocity: float, dt: float, budget_s: float = 12.0, max_missions: int = 100000):
