@@ -33,6 +33,11 @@ def _worker(rank, world, port, out_dir):
         np.save(os.path.join(out_dir, "counts.npy"), np.array(counts))
     else:
         assert allrows is None
+    # the same block split into many small messages (what a > 1 GiB block does under RCCL)
+    split, c_split = gather_rows(torch.from_numpy(rows), dst=0, max_message_bytes=7 * 88)
+    assert c_split == counts
+    if rank == 0:
+        assert torch.equal(split, allrows)
     # an empty shard must not dead-lock the gather
     empty = torch.zeros((0 if rank == 1 else 3, 11), dtype=torch.float64)
     g2, c2 = gather_rows(empty, dst=0)

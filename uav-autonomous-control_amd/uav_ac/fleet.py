@@ -349,11 +349,12 @@ def shard_bounds(B: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_rows(rows, dst: int = 0, group=None):
+def gather_rows(rows, dst: int = 0, group=None, max_message_bytes: int = 1 << 30):
     """Gather ragged (n_r, C) row blocks to `dst` with point-to-point sends (one direct xGMI link per
     peer into the root; a ring all-gather would push 7/8 of the total through every link).
 
-    Works on CPU tensors with gloo and on GPU tensors with nccl (= RCCL).  Returns (all_rows,
+    Works on CPU tensors with gloo and on GPU tensors with nccl (= RCCL).  A rank's block travels as
+    messages of at most `max_message_bytes` (whole rows), all posted in one group.  Returns (all_rows,
     counts) on dst and (None, counts) elsewhere.
     """
     torch = _torch()
@@ -366,17 +367,25 @@ def gather_rows(rows, dst: int = 0, group=None):
     if world == 1:
         return rows, counts
     peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    row_bytes = max(1, rows.element_size() * int(np.prod(rows.shape[1:], dtype=np.int64)))
+    step = max(1, int(max_message_bytes) // row_bytes)             # rows per message, same on both ends
+
+    def pieces(count):
+        return [(a, min(a + step, count)) for a in range(0, count, step)]
+
     if rank == dst:
         out = torch.empty((sum(counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         offs = np.concatenate([[0], np.cumsum(counts)])
         out[offs[dst]:offs[dst + 1]].copy_(rows)
         # one grouped launch: under RCCL the receives run concurrently, one per direct xGMI link into the root
-        ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], peer(r), group)
-               for r in range(world) if r != dst and counts[r] > 0]
+        ops = [dist.P2POp(dist.irecv, out[offs[r] + a:offs[r] + b], peer(r), group)
+               for r in range(world) if r != dst for a, b in pieces(counts[r])]
         for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         return out, counts
     if counts[rank] > 0:
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, rows.contiguous(), peer(dst), group)]):
+        mine = rows.contiguous()
+        ops = [dist.P2POp(dist.isend, mine[a:b], peer(dst), group) for a, b in pieces(counts[rank])]
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
     return None, counts
