@@ -41,6 +41,7 @@ VELOCITY, DT, F = 3.0, 0.01, 10
 # priced against the vector fp64 peak of MI355X_MICROARCH.md (78.6 TFLOP/s = 39.3 T lane-FMA/s).
 FP64_VALU_PER_TICK = 245
 FP64_LANE_INSTR_PEAK = 39.3e12
+GATHER_TIMEOUT_S = 240
 
 
 def missions(B_total, m, lo, hi):
@@ -103,11 +104,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # UAVAC_BENCH_BACKEND=gloo is a rehearsal switch: it lets several ranks share one GPU (RCCL refuses that), so
+    # the N > 1 control flow can be exercised on a 1-GPU box.  The driver's runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("UAVAC_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B, m = args.batch, SEGMENTS
     eng = Engine(dev)
@@ -174,9 +182,67 @@ def main():
     frac_kept = float(kept.double().mean())
     finite_kept = bool(torch.isfinite(fleet.state[:, kept]).all())
 
-    # final gather of the sampled trajectories to rank 0 (north_star: the only collective)
+    out = None
+    if rank == 0:
+        total_ticks = float(world) * B * TICKS * args.steps
+        value = total_ticks / elapsed
+        roll_bytes = Fleet.algorithmic_bytes(B, CHUNK, F)
+        achieved = roll_bytes / roll_avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and B == B_PER_GPU:
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("control_rollout_bytes_per_launch")
+        out = {
+            "metric": "UAV control-steps/sec at batch=65536",
+            "value": value,
+            "unit": "UAV control-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch 65536 UAVs/GPU, 12-segment missions with start/end "
+                                   "time factor 1.5, min-snap solve+sample then 10000 fused controller+dynamics ticks "
+                                   "(10 launches x 1000 ticks, 13-f64 state logged every tick)",
+                       "batch_per_gpu": B, "segments": m, "ticks": TICKS, "ticks_per_launch": CHUNK,
+                       "velocity": VELOCITY, "dt": DT, "inner_per_outer": F, "rows": plan.total_rows,
+                       "parallelism": f"missions sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "control_rollout_kernel<1, true, false, false>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": roll_bytes, "avg_launch_ms": roll_avg_s * 1e3,
+                         "fp64_valu": {"lane_instr_per_tick": FP64_VALU_PER_TICK,
+                                       "achieved": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s,
+                                       "peak": FP64_LANE_INSTR_PEAK, "unit": "fp64 lane-instr/s",
+                                       "frac": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s / FP64_LANE_INSTR_PEAK}},
+            "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
+                        "ms_solve_plus_sample": plan_avg_s * 1e3,
+                        "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes": plan.algorithmic_bytes}},
+            "checks": {"frac_uavs_within_0.5m_of_target_row": frac_kept, "tracking_lanes_finite": finite_kept,
+                       "all_trajectory_cursors_exact": cursor_ok},
+        }
+
+    # final gather of the sampled trajectories to rank 0 (north_star: the only collective).  The timed result is
+    # complete before it starts; a watchdog makes sure the result line still gets printed if the exchange stalls.
     gather_ms, gather_err = None, None
     if world > 1:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["gather_error"] = f"no completion within {GATHER_TIMEOUT_S} s"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(GATHER_TIMEOUT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             barrier()
             g0 = time.perf_counter()
@@ -188,56 +254,19 @@ def main():
             del gathered
         except Exception as exc:                      # the timed result above must survive a collective problem
             gather_err = f"{type(exc).__name__}: {exc}"
+        watchdog.cancel()
+
+    def leave():
+        if world > 1:
+            if gather_err is None:
+                dist.destroy_process_group()
+            else:                                     # a communicator that failed once may not shut down cleanly
+                sys.stdout.flush()
+                os._exit(0)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        leave()
         return
-
-    total_ticks = float(world) * B * TICKS * args.steps
-    value = total_ticks / elapsed
-    roll_bytes = Fleet.algorithmic_bytes(B, CHUNK, F)
-    achieved = roll_bytes / roll_avg_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath) and B == B_PER_GPU:
-        with open(tpath) as fh:
-            traffic = json.load(fh).get("control_rollout_bytes_per_launch")
-    out = {
-        "metric": "UAV control-steps/sec at batch=65536",
-        "value": value,
-        "unit": "UAV control-steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[2]: batch 65536 UAVs/GPU, 12-segment missions with start/end "
-                               "time factor 1.5, min-snap solve+sample then 10000 fused controller+dynamics ticks "
-                               "(10 launches x 1000 ticks, 13-f64 state logged every tick)",
-                   "batch_per_gpu": B, "segments": m, "ticks": TICKS, "ticks_per_launch": CHUNK,
-                   "velocity": VELOCITY, "dt": DT, "inner_per_outer": F, "rows": plan.total_rows,
-                   "parallelism": f"missions sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": "control_rollout_kernel<1, true, false, false>", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": roll_bytes, "avg_launch_ms": roll_avg_s * 1e3,
-                     "fp64_valu": {"lane_instr_per_tick": FP64_VALU_PER_TICK,
-                                   "achieved": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s,
-                                   "peak": FP64_LANE_INSTR_PEAK, "unit": "fp64 lane-instr/s",
-                                   "frac": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s / FP64_LANE_INSTR_PEAK}},
-        "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
-                    "ms_solve_plus_sample": plan_avg_s * 1e3,
-                    "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
-                                 "algorithmic_bytes": plan.algorithmic_bytes}},
-        "checks": {"frac_uavs_within_0.5m_of_target_row": frac_kept, "tracking_lanes_finite": finite_kept,
-                   "all_trajectory_cursors_exact": cursor_ok},
-    }
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
         out["gather_GBps_into_root"] = (world - 1) * plan.total_rows * 88 / (gather_ms * 1e-3) / 1e9
@@ -245,9 +274,8 @@ def main():
         out["gather_error"] = gather_err
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(eng, wps)
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    leave()
 
 
 if __name__ == "__main__":
