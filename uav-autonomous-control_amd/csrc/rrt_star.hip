@@ -10,7 +10,7 @@
 // neighbourhood scan with the segment-vs-cuboid slab test per candidate edge (:150-156, :231-274), the
 // cost-to-come walks of all neighbours at once (:163-186) and the re-wiring test (:207-229), which is applied in
 // list order exactly as the sequential loop would (first improving neighbour, then the ones after it are
-// re-evaluated on the modified tree).  Tree, edge lengths and the neighbour list live in LDS (48 B per node)
+// re-evaluated on the modified tree).  Tree, edge lengths and the neighbour list live in LDS (52 B per node)
 // when they fit, in HBM scratch otherwise.
 //
 // Arithmetic that decides branches is the reference's, operation for operation: np.linalg.norm of a 3-vector
@@ -61,20 +61,33 @@ __device__ __forceinline__ bool slab_hit(double a0, double a1, double a2, double
     return hit;
 }
 
+// Both end points beyond the same face of the cuboid by a clear margin: the slab test below is certain to say
+// "no intersection" (t_low > 1 or t_high < 0 on that axis by far more than rounding can undo), so its six
+// divisions are skipped.  The margin keeps the shortcut exact: inside it the full test decides.
+__device__ __forceinline__ bool clearly_apart(double a, double b, double low, double high) {
+    const double margin = 1e-6 + 1e-9 * fabs(b - a);
+    return (a < low - margin && b < low - margin) || (a > high + margin && b > high + margin);
+}
+
 // RRTStar._is_valid_connection (rrt.py:231-243)
 __device__ __forceinline__ bool valid_connection(double a0, double a1, double a2, double b0, double b1, double b2,
                                                  const double *__restrict__ cuboids, int n_obs) {
-    for (int o = 0; o < n_obs; ++o)
-        if (slab_hit(a0, a1, a2, b0, b1, b2, cuboids + 6 * o)) return false;
+    for (int o = 0; o < n_obs; ++o) {
+        const double *c = cuboids + 6 * o;
+        if (clearly_apart(a0, b0, c[0], c[1]) || clearly_apart(a1, b1, c[2], c[3]) || clearly_apart(a2, b2, c[4], c[5]))
+            continue;
+        if (slab_hit(a0, a1, a2, b0, b1, b2, c)) return false;
+    }
     return true;
 }
 
 struct Tree {
     double *nodes;   // [cap][3]
     int *canon;      // [cap]
-    int *par;        // [cap] the dict: parent key of a key, -1 when the dict has no such key
+    int *par;        // [cap] the dict (HBM, the `parent` output): parent key of a key, -1 when there is no such key
     int *up;         // [cap] walk link of a key: parent key, -1 no entry, -2 the key is (by value) the start
     double *elen;    // [cap] |key - parent(key)|
+    double *cc;      // [cap] cost-to-come of a key as last walked, NaN = not known for the present tree
     int *nbr;        // [cap] neighbour list of the iteration
     int cap;
 };
@@ -90,6 +103,23 @@ __device__ __forceinline__ double cost_to_come(const Tree &t, int c, bool &key_e
         c = u;
     }
     return cost;
+}
+
+// The same value without the walk when this key was walked since the tree last changed under an existing key.
+// (A cost-to-come is the edge lengths summed from the node towards the start, so it cannot be derived from the
+// parent's value -- different association -- but it can be remembered while the chain stays as it is.)
+__device__ __forceinline__ double cost_to_come_cached(const Tree &t, int c, bool &key_err) {
+    double v = t.cc[c];
+    if (v == v) return v;
+    v = cost_to_come(t, c, key_err);
+    t.cc[c] = v;
+    return v;
+}
+
+__device__ __forceinline__ void forget_costs(const Tree &t, int n, int lane) {
+    __syncthreads();
+    for (int e = lane; e < n; e += W) t.cc[e] = __builtin_nan("");
+    __syncthreads();
 }
 
 __device__ __forceinline__ int first_lane(unsigned long long m) { return __ffsll((long long)m) - 1; }
@@ -120,20 +150,21 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
     Tree t;
     t.cap = cap;
     int32_t *best_parent = g_best_parent + b * capz;
+    t.par = g_parent + b * capz;
     if (use_lds) {
         t.nodes = lds;
         t.elen = lds + 3 * capz;
-        t.canon = reinterpret_cast<int *>(lds + 4 * capz);
-        t.par = t.canon + capz;
-        t.up = t.par + capz;
+        t.cc = lds + 4 * capz;
+        t.canon = reinterpret_cast<int *>(lds + 5 * capz);
+        t.up = t.canon + capz;
         t.nbr = t.up + capz;
     } else {
-        double *ws = scratch + (size_t)b * 2 * capz;       // elen [cap] f64, up [cap] i32, nbr [cap] i32
+        double *ws = scratch + (size_t)b * 3 * capz;       // elen, cc [cap] f64, up, nbr [cap] i32
         t.nodes = g_nodes + b * 3 * capz;
         t.canon = g_canon + b * capz;
-        t.par = g_parent + b * capz;
         t.elen = ws;
-        t.up = reinterpret_cast<int *>(ws + capz);
+        t.cc = ws + capz;
+        t.up = reinterpret_cast<int *>(ws + 2 * capz);
         t.nbr = t.up + capz;
     }
     int *parent = t.par;
@@ -151,6 +182,7 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
         t.canon[0] = 0;
         t.up[0] = -2;
         t.elen[0] = 0.0;
+        t.cc[0] = 0.0;
     }
     __syncthreads();
 
@@ -158,7 +190,7 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
     int goal_key = (bits_equal(start[0], goal[0]) && bits_equal(start[1], goal[1]) && bits_equal(start[2], goal[2])) ? 0 : -1;
     double old_cost = INFINITY;
     int counter = 0, status = RRT_OK, best_n = 0, it = 0;
-    bool have_best = false;
+    bool have_best = false, goal_linked = false;
     const double *smp = samples + (size_t)b * max_iter * 3;
 
     for (it = 0; it < max_iter; ++it) {
@@ -183,8 +215,10 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
             nw2 = round2(p[2] + (nw2 - p[2]) * step / dmin);
         }
 
-        // ---- _find_valid_neighbors (rrt.py:150-156) + the dict key of the new node
-        int n_nbr = 0, key = -1;
+        // ---- _find_valid_neighbors (rrt.py:150-156) + the dict key of the new node.  Two passes: the radius test
+        // over all entries compacts the few candidates (in list order) into t.nbr, then the segment-vs-cuboid
+        // tests run on full lanes of candidates only and compact in place.
+        int n_cand = 0, key = -1;
         for (int base = 0; base < n; base += W) {
             const int e = base + lane;
             bool in = false, same = false;
@@ -192,13 +226,31 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
                 const double *p = t.nodes + 3 * e;
                 const double p0 = p[0], p1 = p[1], p2 = p[2];
                 same = bits_equal(p0, nw0) && bits_equal(p1, nw1) && bits_equal(p2, nw2);
-                in = norm3(p0 - nw0, p1 - nw1, p2 - nw2) <= radius &&
-                     valid_connection(p0, p1, p2, nw0, nw1, nw2, cuboids, n_obs);
+                in = norm3(p0 - nw0, p1 - nw1, p2 - nw2) <= radius;
             }
             const unsigned long long m_in = __ballot(in), m_same = __ballot(same);
-            if (in) t.nbr[n_nbr + __popcll(m_in & ((1ull << lane) - 1ull))] = e;
-            n_nbr += __popcll(m_in);
+            if (in) t.nbr[n_cand + __popcll(m_in & ((1ull << lane) - 1ull))] = e;
+            n_cand += __popcll(m_in);
             if (key < 0 && m_same) key = base + first_lane(m_same);
+        }
+        __syncthreads();
+        int n_nbr = n_cand;
+        if (n_obs > 0) {
+            n_nbr = 0;
+            for (int base = 0; base < n_cand; base += W) {
+                const int i = base + lane;
+                bool ok = false;
+                int e = 0;
+                if (i < n_cand) {
+                    e = t.nbr[i];
+                    const double *p = t.nodes + 3 * e;
+                    ok = valid_connection(p[0], p[1], p[2], nw0, nw1, nw2, cuboids, n_obs);
+                }
+                const unsigned long long m_ok = __ballot(ok);
+                __syncthreads();                                  // every lane holds its e before slots are rewritten
+                if (ok) t.nbr[n_nbr + __popcll(m_ok & ((1ull << lane) - 1ull))] = e;
+                n_nbr += __popcll(m_ok);
+            }
         }
         __syncthreads();
         if (n_nbr == 0) continue;
@@ -212,23 +264,26 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
             if (i < n_nbr) {
                 const int e = t.nbr[i];
                 const double *p = t.nodes + 3 * e;
-                const double c = cost_to_come(t, t.canon[e], kerr) + norm3(p[0] - nw0, p[1] - nw1, p[2] - nw2);
+                const double c = cost_to_come_cached(t, t.canon[e], kerr) + norm3(p[0] - nw0, p[1] - nw1, p[2] - nw2);
                 if (c < cbest) { cbest = c; ibest = i; }
             }
         }
         wave_argmin(cbest, ibest);
+        __syncthreads();                                  // costs remembered by other lanes are visible from here on
         if (ibest == 0x7fffffff) ibest = 0;
         const int best = t.nbr[ibest];
         const double bp0 = t.nodes[3 * best], bp1 = t.nodes[3 * best + 1], bp2 = t.nodes[3 * best + 2];
         const int best_key = t.canon[best];
 
-        // ---- _update_tree (rrt.py:188-205)
+        // ---- _update_tree (rrt.py:188-205).  pk = key of tree[key(new_node)] afterwards (-1: no such entry)
+        int pk = -1;
+        bool linked = false;
         if (!(bp0 == nw0 && bp1 == nw1 && bp2 == nw2)) {
             bool link = true;
             const double edge = norm3(nw0 - bp0, nw1 - bp1, nw2 - bp2);
             if (key >= 0 && parent[key] >= 0) {
-                const double current = cost_to_come(t, key, kerr);
-                const double cand = cost_to_come(t, best_key, kerr) + edge;
+                const double current = cost_to_come_cached(t, key, kerr);
+                const double cand = cost_to_come_cached(t, best_key, kerr) + edge;
                 if (current <= cand) link = false;
             }
             if (link) {
@@ -241,21 +296,26 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
                     parent[key] = best_key;
                     t.up[key] = (nw0 == start[0] && nw1 == start[1] && nw2 == start[2]) ? -2 : best_key;
                     t.elen[key] = edge;
+                    t.cc[key] = __builtin_nan("");
                 }
                 if (fresh && bits_equal(nw0, goal[0]) && bits_equal(nw1, goal[1]) && bits_equal(nw2, goal[2]) && goal_key < 0)
                     goal_key = key;
                 ++n;
                 __syncthreads();
+                if (!fresh) forget_costs(t, n, lane);                 // an existing key changed parent
+                linked = true;
+                pk = best_key;
             }
         }
+        if (!linked && key >= 0) pk = parent[key];
+        if (key >= 0 && key == goal_key && pk >= 0) goal_linked = true;
 
         // ---- _rewire_safely (rrt.py:207-229)
         bool has_rewired = false;
         if (key < 0) {
             kerr = true;            // the new node equals its best neighbour by value, not by key: no dict entry
         } else {
-            const double new_cost = cost_to_come(t, key, kerr);
-            const int pk = parent[key];                               // self.tree[key(new_node)]
+            const double new_cost = cost_to_come_cached(t, key, kerr);
             double q0 = 0.0, q1 = 0.0, q2 = 0.0;
             if (pk >= 0) { q0 = t.nodes[3 * pk]; q1 = t.nodes[3 * pk + 1]; q2 = t.nodes[3 * pk + 2]; }
             for (int base = 0; base < n_nbr; base += W) {
@@ -281,7 +341,7 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
                 int done_upto = -1;                                   // lanes <= done_upto have had their turn
                 while (true) {
                     bool want = false;
-                    if (cand && lane > done_upto) want = through < cost_to_come(t, c, kerr);
+                    if (cand && lane > done_upto) want = through < cost_to_come_cached(t, c, kerr);
                     const unsigned long long m = __ballot(want);
                     if (!m) break;
                     const int L = first_lane(m);
@@ -289,15 +349,15 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
                     if (lane == L) { parent[c] = key; t.up[c] = key; t.elen[c] = edge; }
                     has_rewired = true;
                     done_upto = L;
-                    __syncthreads();
+                    forget_costs(t, n, lane);                         // an existing key changed parent
                 }
             }
         }
         if (__ballot(kerr)) { status = RRT_KEY_ERROR; ++it; break; }
 
         // ---- _is_path_found + get_path (rrt.py:276-301)
-        if (goal_key >= 0 && parent[goal_key] >= 0) {
-            const double cost = cost_to_come(t, goal_key, kerr);
+        if (goal_linked) {
+            const double cost = cost_to_come_cached(t, goal_key, kerr);
             if (has_rewired && cost > old_cost) { status = RRT_COST_INCREASED; ++it; break; }
             if (cost < old_cost) {
                 __syncthreads();
@@ -320,8 +380,8 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
         double *gn = g_nodes + b * 3 * capz;
         for (int i = lane; i < 3 * n; i += W) gn[i] = t.nodes[i];
         for (int i = 3 * n + lane; i < 3 * cap; i += W) gn[i] = 0.0;
-        int32_t *gc = g_canon + b * capz, *gp = g_parent + b * capz;
-        for (int e = lane; e < cap; e += W) { gc[e] = t.canon[e]; gp[e] = t.par[e]; }
+        int32_t *gc = g_canon + b * capz;
+        for (int e = lane; e < cap; e += W) gc[e] = t.canon[e];
     } else {
         for (int i = 3 * n + lane; i < 3 * cap; i += W) t.nodes[i] = 0.0;
     }
@@ -400,10 +460,10 @@ __global__ void rrt_steer_kernel(const double *__restrict__ sample, const double
     out[3 * (size_t)e] = n0; out[3 * (size_t)e + 1] = n1; out[3 * (size_t)e + 2] = n2;
 }
 
-constexpr size_t kLdsBytesPerNode = 3 * 8 + 8 + 4 * 4;     // nodes, elen, canon/par/up/nbr
+constexpr size_t kLdsBytesPerNode = 3 * 8 + 8 + 8 + 3 * 4;     // nodes, elen, cc, canon/up/nbr
 constexpr size_t kLdsLimit = 160 * 1024;
 
-size_t scratch_doubles_per_problem(int cap) { return 2 * (size_t)cap; }
+size_t scratch_doubles_per_problem(int cap) { return 3 * (size_t)cap; }
 
 struct DevBuf {
     void *p = nullptr;
