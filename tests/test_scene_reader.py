@@ -60,3 +60,15 @@ def test_broken_scenes_raise_like_the_reference(tmp_path, old, new, msg):
     p.write_text(text.replace(old, new))
     with pytest.raises(ValueError, match=msg):
         MujocoSimulation(p)
+
+
+def test_config_helpers_like_the_reference():
+    """uav_ac.utils.get_config / parse_array (reference utils.py:8-28, config.ini:2,7,9)."""
+    import configparser
+    from uav_ac import utils
+    cfg, flight = utils.get_config()
+    assert cfg.getint("frequency") == 10
+    assert flight.getfloat("velocity") == 3.0 and flight.getfloat("min_dist_target") == 0.5
+    parser = configparser.ConfigParser()
+    parser.read_string("[S]\nlimits = [[0, 0, 0], [10, 10, 10]]\n")
+    assert np.array_equal(utils.parse_array(parser["S"], "limits"), np.array([[0, 0, 0], [10, 10, 10]]))

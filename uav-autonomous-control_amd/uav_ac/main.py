@@ -146,7 +146,10 @@ def main(model_path=None) -> None:
     path = model_path or (sys.argv[1] if len(sys.argv) > 1 else None)
     if path is None:
         raise SystemExit("usage: python -m uav_ac.main <scene.xml>")
-    out = fly_mission(path)
+    from . import utils
+    cfg, cfg_flight = utils.get_config()                     # reference main.py:88-93
+    out = fly_mission(path, velocity=cfg_flight.getfloat("velocity"), frequency=cfg.getint("frequency"),
+                      min_distance_target=cfg_flight.getfloat("min_dist_target"))
     print(f"Flight finished {out['distance_to_goal']:.2f} m away from the goal "
           f"({'reached' if out['goal_reached'] else 'missed'}).")
     if out["collision_detected"]:
