@@ -125,7 +125,8 @@ def main():
                 all_nodes=np.array(rrt.all_nodes, dtype=float).reshape(-1, 3),
                 tree_parent=tree_as_parents(rrt, rrt.tree), best_tree_parent=best_tree_par,
                 best_path=np.zeros((0, 3)) if rrt.best_path is None else rrt.best_path,
-                best_cost=np.nan if rrt.best_path is None else RRTStar.path_cost(list(rrt.best_path[::-1])))
+                best_cost=np.nan if rrt.best_path is None else RRTStar.path_cost(list(rrt.best_path[::-1])),
+                simplified_path=np.zeros((0, 3)) if rrt.best_path is None else rrt.simplify_path(rrt.best_path))
             tail = f"ERROR {error}" if error else f"path of {len(rrt.best_path)} nodes, cost {res['best_cost']:.4f}"
             print(f"{name}/{seed}: {len(samples)} iterations, {len(rrt.all_nodes)} nodes, {tail}")
 

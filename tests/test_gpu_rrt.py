@@ -93,6 +93,8 @@ def test_facade_run_reproduces_seeded_reference_run(capsys):
                 assert np.array_equal(rrt.tree[k], g["tree_parent"][e])
         path, cost = rrt.get_path(rrt.best_tree)
         assert np.array_equal(path, g["best_path"]) and cost == float(g["best_cost"])
+        assert np.array_equal(rrt.simplify_path(rrt.best_path), g["simplified_path"])
+        assert len(g["simplified_path"]) <= len(g["best_path"])
         # generator state: the next draws equal what follows the recorded sequence
         after = np.random.uniform(0, 1)
         np.random.seed(int(g["seed"]))
@@ -139,7 +141,7 @@ def test_batch_matches_oracle_on_random_problems(max_iter, n_obs):
 
 
 def test_large_tree_takes_the_scratch_path():
-    """max_iterations too large for LDS (48 B per node > 160 KB): the same kernel on HBM scratch, same results."""
+    """max_iterations too large for LDS (52 B per node > 160 KB): the same kernel on HBM scratch, same results."""
     from oracle import c_oracle as co
     from uav_ac.planning.rrt import draw_random_nodes, rrt_star_batch
     max_iter = 3600
