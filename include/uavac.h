@@ -255,6 +255,10 @@ int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p
                                int p1_is_single, int E, double *out);
 int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, int p1_is_single,
                            int E, double *out);
+/* RRTStar.path_cost (rrt.py:84-91): the edge lengths of the polyline path[n][3] summed in path
+ * order (also the accumulation of _cost_to_come, :163-173, on the node -> start chain). */
+int uavac_rrt_path_cost_dev(uavac_ctx *ctx, const double *path, int n, double *cost);
+int uavac_rrt_path_cost(uavac_ctx *ctx, const double *path, int n, double *cost);
 /* RRTStar._adapt_random_node_position (rrt.py:140-148) for E (sample, nearest node) pairs:
  * out[e] = sample[e] when within step of nearest[e], else the rounded point at step from it. */
 int uavac_rrt_steer_dev(uavac_ctx *ctx, const double *sample, const double *nearest, int E,

@@ -444,6 +444,17 @@ __global__ void rrt_edge_lengths_kernel(const double *__restrict__ p0, const dou
     out[e] = norm3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
 }
 
+// RRTStar.path_cost (rrt.py:84-91): edge lengths of the polyline summed in order (one lane: the order is the result)
+__global__ void rrt_path_cost_kernel(const double *__restrict__ path, int n, double *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double cost = 0.0;
+    for (int i = 0; i + 1 < n; ++i) {
+        const double *a = path + 3 * (size_t)i, *b = a + 3;
+        cost += norm3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
+    }
+    out[0] = cost;
+}
+
 // RRTStar._adapt_random_node_position (rrt.py:140-148) for E (sample, nearest node) pairs
 __global__ void rrt_steer_kernel(const double *__restrict__ sample, const double *__restrict__ nearest, int E,
                                  double step, double *__restrict__ out) {
@@ -542,6 +553,15 @@ int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p
     return UAVAC_OK;
 }
 
+int uavac_rrt_path_cost_dev(uavac_ctx *ctx, const double *path, int n, double *cost) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (n < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
+    if (!cost || (n > 0 && !path)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    hipLaunchKernelGGL(rrt_path_cost_kernel, dim3(1), dim3(64), 0, ctx->stream, path, n, cost);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
 int uavac_rrt_steer_dev(uavac_ctx *ctx, const double *sample, const double *nearest, int E, double step, double *out) {
     if (!ctx) return UAVAC_EINVAL;
     if (E < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
@@ -633,6 +653,20 @@ int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, i
     if (int rc = uavac_rrt_edge_lengths_dev(ctx, d0.as<double>(), d1.as<double>(), p1_is_single, E, dout.as<double>()))
         return rc;
     UAVAC_HIP(ctx, hipMemcpyAsync(out, dout.p, 8 * zE, hipMemcpyDeviceToHost, ctx->stream));
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UAVAC_OK;
+}
+
+int uavac_rrt_path_cost(uavac_ctx *ctx, const double *path, int n, double *cost) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (n < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
+    if (!cost || (n > 0 && !path)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    DevBuf dp, dc;
+    UAVAC_HIP(ctx, dp.alloc(24 * (size_t)n));
+    UAVAC_HIP(ctx, dc.alloc(8));
+    if (n > 0) UAVAC_HIP(ctx, hipMemcpyAsync(dp.p, path, 24 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = uavac_rrt_path_cost_dev(ctx, dp.as<double>(), n, dc.as<double>())) return rc;
+    UAVAC_HIP(ctx, hipMemcpyAsync(cost, dc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }

@@ -144,6 +144,14 @@ def _edge_lengths(p0, p1) -> np.ndarray:
     return out
 
 
+def _polyline_length(points) -> float:
+    """Edge lengths of the polyline summed in order (RRTStar.path_cost's loop), on the GPU."""
+    pts = nat.as_f64(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+    out = np.zeros(1)
+    ctx().call("uavac_rrt_path_cost", nat.np_ptr(pts), pts.shape[0], nat.np_ptr(out))
+    return out[0]
+
+
 def _segment_hits(p0, p1, cuboids) -> np.ndarray:
     p0 = nat.as_f64(np.asarray(p0, dtype=np.float64).reshape(-1, 3))
     p1 = nat.as_f64(np.asarray(p1, dtype=np.float64).reshape(-1, 3))
@@ -213,14 +221,9 @@ class RRTStar:
     @staticmethod
     def path_cost(path):
         """
-        Calculate the cost of the path (rrt.py:84-91): edge lengths from the GPU, summed in path order
+        Calculate the cost of the path (rrt.py:84-91)
         """
-        path = np.asarray(path, dtype=np.float64).reshape(-1, 3)
-        cost = 0
-        if len(path) > 1:
-            for length in _edge_lengths(path[:-1], path[1:]):
-                cost += length
-        return cost
+        return _polyline_length(path)
 
     def simplify_path(self, path: np.ndarray) -> np.ndarray:
         """
@@ -287,20 +290,13 @@ class RRTStar:
 
     def _cost_to_come(self, node: np.ndarray) -> float:
         """
-        Cost of the path from the start to `node` following the tree edges (rrt.py:163-173): the chain is collected
-        from the dict, its edge lengths come from the GPU in one call and are summed in walking order.
+        Cost of the path from the start to `node` following the tree edges (rrt.py:163-173): the chain node ->
+        start is read off the dict, its length is accumulated on the GPU in walking order.
         """
         chain = [np.asarray(node, dtype=float)]
-        current = node
-        while not np.array_equal(current, self.start):
-            current = self.tree[RRTStar._node_key(current)]
-            chain.append(np.asarray(current, dtype=float))
-        cost = 0.0
-        if len(chain) > 1:
-            chain = np.asarray(chain)
-            for length in _edge_lengths(chain[1:], chain[:-1]):
-                cost += length
-        return cost
+        while not np.array_equal(chain[-1], self.start):
+            chain.append(np.asarray(self.tree[RRTStar._node_key(chain[-1])], dtype=float))
+        return float(_polyline_length(chain))
 
     def _find_best_neighbor(self, neighbors, new_node):
         """
