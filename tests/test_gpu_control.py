@@ -449,3 +449,23 @@ def test_outer_loop_every_F_ticks_and_cmd_log_only(eng, nat, F):
         assert col_err(clog[:, :, b].cpu().numpy(), c_ref) < TOL
         assert int(fleet.trajectory_index[b]) == istate[0] == min((K + F - 1) // F, len(traj) - 1)
         assert col_err(fleet.state[:, b].cpu().numpy()[None], state[None]) < TOL
+
+
+def test_logged_rollout_beyond_one_launch_is_split_without_a_trace(eng):
+    """B > 65 536 with a log goes out as consecutive launches over column ranges (one workgroup per SIMD each):
+    the lanes of the second range equal, bit for bit, the same missions flown as a batch of their own, the log rows
+    of both ranges are filled, and the ragged tail workgroup (B not a multiple of 64) is handled."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    B, K, cut = 65536 + 4101, 40, 65536 - 300
+    wps = mo.synthetic_missions(B, 2)
+    big = eng.fleet(eng.plan(wps, 3.0, 0.01))
+    slog, clog = big.rollout(K, state_log=True, cmd_log=True)
+    small = eng.fleet(eng.plan(wps[cut:], 3.0, 0.01))
+    slog2, clog2 = small.rollout(K, state_log=True, cmd_log=True)
+    assert torch.equal(slog[:, :, cut:], slog2) and torch.equal(clog[:, :, cut:], clog2)
+    assert torch.equal(big.state[:, cut:], small.state) and torch.equal(big.istate[:, cut:], small.istate)
+    assert bool((slog[:, 3:7].norm(dim=1) - 1).abs().max() < 1e-12)          # every column of every tick was written
+    nolog = eng.fleet(eng.plan(wps, 3.0, 0.01))
+    nolog.rollout(K)                                                          # one launch, no log: same states
+    assert torch.equal(nolog.state, big.state)
