@@ -333,7 +333,9 @@ int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, cons
     // measured 15 % slower at B = 65 536: a single wave cannot issue a CU's 52 stores per tick fast enough.
     // Two compute waves with the store wave moving 16 B per lane -- 13 x 1 KB wave stores per tick instead of
     // 26 x 512 B -- were 17 % slower too, 1.47 vs 1.25 ms on the same box: the per-tick barrier then couples
-    // two compute waves.)  The log rows want B to be a multiple of 16 (128-B lines): B = 65 534 runs at half
+    // two compute waves.  Replacing the per-tick barrier by a ring of 4 slabs with produced / consumed counters in
+    // LDS, so that the compute wave may run 4 ticks ahead of a stalled store wave, was slower as well: 1.35 vs
+    // 1.26 ms -- the hand-over is not what limits the kernel.)  The log rows want B to be a multiple of 16 (128-B lines): B = 65 534 runs at half
     // the rate of B = 65 536 because every 512-B wave store then straddles two partially written lines.
     launch_cw<1>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs);
     UAVAC_HIP(ctx, hipGetLastError());
