@@ -63,6 +63,8 @@ def lib():
         _lib.oracle_rrt_distances.argtypes = [_P, C.c_int, _P, _P]
         _lib.oracle_rrt_edge_lengths.restype = None
         _lib.oracle_rrt_edge_lengths.argtypes = [_P, _P, C.c_int, C.c_int, _P]
+        _lib.oracle_rrt_segment_hits.restype = None
+        _lib.oracle_rrt_segment_hits.argtypes = [_P, _P, C.c_int, _P, C.c_int, _P]
         _lib.oracle_rrt_steer.restype = None
         _lib.oracle_rrt_steer.argtypes = [_P, _P, C.c_double, _P]
         _lib.oracle_rrt_star.restype = C.c_int
@@ -145,6 +147,15 @@ def rrt_edge_lengths(p0, p1):
     out = np.empty(len(p0))
     lib().oracle_rrt_edge_lengths(_p(p0), _p(p1), int(p1.ndim == 1), len(p0), _p(out))
     return out
+
+
+def rrt_segment_hits(p0, p1, cuboids):
+    p0 = np.ascontiguousarray(p0, dtype=np.float64).reshape(-1, 3)
+    p1 = np.ascontiguousarray(p1, dtype=np.float64).reshape(-1, 3)
+    cub = np.ascontiguousarray(cuboids, dtype=np.float64).reshape(-1, 6)
+    hit = np.zeros(len(p0), dtype=np.int32)
+    lib().oracle_rrt_segment_hits(_p(p0), _p(p1), len(p0), _p(cub), len(cub), _p(hit))
+    return hit.astype(bool)
 
 
 def rrt_steer(sample, nearest, step: float):

@@ -238,3 +238,8 @@ void oracle_rrt_steer(const double *sample, const double *nearest, double step, 
     for (int a = 0; a < 3; ++a)
         out[a] = d > step ? round2(nearest[a] + (sample[a] - nearest[a]) * step / d) : sample[a];
 }
+
+/* hit[e] = 1 when segment p0[e] -> p1[e] crosses any of the n_obs cuboids (not a valid connection) */
+void oracle_rrt_segment_hits(const double *p0, const double *p1, int n, const double *cuboids, int n_obs, int *hit) {
+    for (int e = 0; e < n; ++e) hit[e] = !valid_connection(p0 + 3 * e, p1 + 3 * e, cuboids, n_obs);
+}

@@ -183,6 +183,41 @@ def test_primitives_match_known_answers():
         assert np.array_equal(got, co.rrt_steer(g["a"][i], g["b"][i], 2.0))
 
 
+def test_segment_test_shortcut_never_changes_an_answer():
+    """The kernel skips a cuboid's slab test when both end points lie beyond one of its faces by a margin
+    (1e-6 + 1e-9 |d|).  Adversarial edges -- end points ON faces, within 1e-5 .. 1e-9 .. one ulp of them, inside,
+    axis-parallel, degenerate, very long -- against the oracle, which always runs the full test."""
+    from oracle import c_oracle as co
+    from uav_ac.planning import rrt as R
+    rng = np.random.default_rng(77)
+    cub = np.array([[1.0, 2.0, -1.0, 3.0, 0.5, 0.75], [-4.0, -3.99, -10.0, 10.0, -10.0, 10.0],
+                    [5.0, 5.0, 0.0, 1.0, 0.0, 1.0], [100.0, 250.0, 100.0, 250.0, -3.0, 3.0]])
+    n = 200000
+    which = rng.integers(0, len(cub), n)
+    face = cub[which]
+    lo, hi = face[:, 0::2], face[:, 1::2]
+    a = rng.uniform(lo - 2.0, hi + 2.0)
+    b = rng.uniform(lo - 2.0, hi + 2.0)
+    offs = np.array([0.0, 1e-5, -1e-5, 1e-6, -1e-6, 2e-6, -2e-6, 1e-7, -1e-7, 1e-9, -1e-9, 1e-12, -1e-12])
+    for pts in (a, b):                                      # snap a third of the coordinates onto / next to a face
+        snap = rng.random((n, 3)) < 0.33
+        side = np.where(rng.random((n, 3)) < 0.5, lo, hi)
+        near = side + rng.choice(offs, (n, 3))
+        ulp = np.nextafter(side, np.where(rng.random((n, 3)) < 0.5, np.inf, -np.inf))
+        near = np.where(rng.random((n, 3)) < 0.2, ulp, near)
+        pts[snap] = near[snap]
+    par = rng.random((n, 3)) < 0.15
+    b[par] = a[par]                                         # axis-parallel and degenerate segments
+    far = rng.random(n) < 0.05
+    b[far] = a[far] + rng.uniform(-1e6, 1e6, (int(far.sum()), 3))
+    got = R._segment_hits(a, b, cub)
+    ref = co.rrt_segment_hits(a, b, cub)
+    assert np.array_equal(got, ref)
+    assert 0.05 < ref.mean() < 0.95
+    for c in cub:                                           # and cuboid by cuboid
+        assert np.array_equal(R._segment_hits(a[:50000], b[:50000], c), co.rrt_segment_hits(a[:50000], b[:50000], c))
+
+
 # ------------------------------------------------------------- upstream tests/unit/planning/test_rrt.py, replayed
 @pytest.fixture
 def rrt_object():
