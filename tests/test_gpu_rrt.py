@@ -140,6 +140,24 @@ def test_batch_matches_oracle_on_random_problems(max_iter, n_obs):
         assert not res.nodes[b, res.n_nodes[b]:].any() and not res.best_path[b, res.best_len[b]:].any()
 
 
+def test_device_resident_entry_point_equals_host_twin():
+    """Engine.rrt_star (torch tensors in and out, uavac_rrt_star_dev) == rrt_star_batch (NumPy, uavac_rrt_star)."""
+    import dataclasses
+    from uav_ac.fleet import Engine
+    from uav_ac.planning.rrt import draw_random_nodes_batch, rrt_star_batch
+    rng = np.random.default_rng(9)
+    B, max_iter = 70, 600
+    lw, up = np.array([0.0, 0.0, 0.0]), np.array([10.0, 10.0, 4.0])
+    starts, goals = rng.uniform(lw, [2, 10, 4], (B, 3)), rng.uniform([8, 0, 0], up, (B, 3))
+    obstacles = np.array([[4.0, 5.0, 5.0, 11.0, -1.0, 5.0], [6.5, 7.0, -1.0, 4.0, -1.0, 5.0]])
+    samples = draw_random_nodes_batch(np.arange(B) + 40, lw, up, np.round(goals, 2), max_iter)
+    host = rrt_star_batch(starts, goals, 1.0, samples, obstacles)
+    dev = Engine("cuda:0").rrt_star(starts, goals, 1.0, samples, obstacles).to_host()
+    for f in dataclasses.fields(host):
+        assert np.array_equal(getattr(host, f.name), getattr(dev, f.name)), f.name
+    assert (host.status == 0).sum() > B // 4
+
+
 def test_large_tree_takes_the_scratch_path():
     """max_iterations too large for LDS (52 B per node > 160 KB): the same kernel on HBM scratch, same results."""
     from oracle import c_oracle as co

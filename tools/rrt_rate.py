@@ -5,7 +5,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
 import numpy as np
 import torch
-from uav_ac import _native as nat
 from uav_ac.planning.rrt import draw_random_nodes_batch
 from oracle import c_oracle as co
 
@@ -23,26 +22,16 @@ t0 = time.perf_counter()
 samples = draw_random_nodes_batch(np.arange(Bmax), lw, up, goals, max_iter)
 print(f"host: drew {Bmax} x {max_iter} nodes in {time.perf_counter() - t0:.1f} s")
 
-dev = torch.device("cuda:0")
-ctx = nat.Context(0)
-ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-P = lambda t: nat._P(t.data_ptr())
-cub = torch.as_tensor(LAB, device=dev)
-cap = max_iter + 1
+from uav_ac.fleet import Engine
+eng = Engine("cuda:0")
+dev = eng.device
 for B in Bs:
-    s = torch.as_tensor(starts[:B], device=dev); g = torch.as_tensor(goals[:B], device=dev)
-    smp = torch.as_tensor(samples[:B], device=dev)
-    nodes = torch.empty((B, cap, 3), dtype=torch.float64, device=dev); path = torch.empty_like(nodes)
-    canon = torch.empty((B, cap), dtype=torch.int32, device=dev); par = torch.empty_like(canon); bpar = torch.empty_like(canon)
-    counts = torch.empty((B, 6), dtype=torch.int32, device=dev); cost = torch.empty(B, dtype=torch.float64, device=dev)
-    def run():
-        ctx.call("uavac_rrt_star_dev", P(s), P(g), B, step, max_iter, P(smp), P(cub), len(LAB), P(nodes), P(canon), P(par),
-                 P(bpar), P(path), P(counts), P(cost))
-    run(); torch.cuda.synchronize()
+    s_, g_, smp = (torch.as_tensor(x[:B], device=dev) for x in (starts, goals, samples))
+    eng.rrt_star(s_, g_, step, smp, LAB); torch.cuda.synchronize()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-    a.record(); run(); b.record(); torch.cuda.synchronize()
-    ms = a.elapsed_time(b)
-    c = counts.cpu().numpy()
+    a.record(); res = eng.rrt_star(s_, g_, step, smp, LAB); b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b)                                   # includes allocating the result tensors
+    c = res.counts.cpu().numpy()
     its = int(c[:, 1].sum())
     print(f"B={B}: {ms:.1f} ms  -> {B / ms * 1e3:.0f} problems/s, {its / ms * 1e3 / 1e6:.2f} M iterations/s; "
           f"found {int((c[:, 2] == 0).sum())}/{B}, mean iterations {c[:, 1].mean():.0f}, mean nodes {c[:, 0].mean():.0f}")

@@ -74,6 +74,28 @@ class RaggedPlan:
         return self.traj[int(ro[0]):int(ro[1])].cpu().numpy().copy()
 
 
+@dataclass
+class RRTDeviceBatch:
+    """Device-resident results of `Engine.rrt_star` (torch tensors; layouts of include/uavac.h).
+    counts[:, k]: 0 n_nodes, 1 iterations begun, 2 status, 3 entries when best_tree was stored, 4 best_path rows,
+    5 dynamic_it_counter."""
+    nodes: "object"
+    canon: "object"
+    parent: "object"
+    best_parent: "object"
+    best_path: "object"
+    counts: "object"
+    best_cost: "object"
+
+    def to_host(self):
+        """-> uav_ac.planning.rrt.RRTBatch (NumPy)."""
+        from .planning.rrt import RRTBatch
+        c = self.counts.cpu().numpy()
+        return RRTBatch(self.nodes.cpu().numpy(), self.canon.cpu().numpy(), self.parent.cpu().numpy(),
+                        self.best_parent.cpu().numpy(), self.best_path.cpu().numpy(), c[:, 0].copy(), c[:, 1].copy(),
+                        c[:, 2].copy(), c[:, 3].copy(), c[:, 4].copy(), c[:, 5].copy(), self.best_cost.cpu().numpy())
+
+
 class Engine:
     """One GPU, one `uavac_ctx`.  Kernels are enqueued on torch's current stream for that device."""
 
@@ -259,6 +281,40 @@ class Engine:
         if bool((plan.status != 0).any()):
             bad = int((plan.status != 0).nonzero()[0])
             raise nat.UavacError(nat.ESINGULAR, f"mission {bad}: singular knot system (repeated waypoint?)")
+
+    # -- RRT* ---------------------------------------------------------------------
+    def rrt_star(self, starts, goals, max_distance: float, samples, obstacles=None) -> "RRTDeviceBatch":
+        """B independent RRT* runs (uav_ac/planning/rrt.py `RRTStar.run`), one wavefront each, inputs and results
+        resident on the GPU.  `samples` (B, max_iterations, 3): the nodes `_generate_random_node` returns, e.g. from
+        `uav_ac.planning.rrt.draw_random_nodes_batch`.  Layouts as documented in include/uavac.h."""
+        torch = self._torch
+        s = self._dev(starts, torch.float64)
+        g = self._dev(goals, torch.float64)
+        smp = self._dev(samples, torch.float64)
+        if s.dim() != 2 or s.shape[1] != 3 or g.shape != s.shape:
+            raise ValueError("starts and goals must both have shape (B, 3)")
+        B = int(s.shape[0])
+        if smp.dim() != 3 or smp.shape[0] != B or smp.shape[2] != 3 or smp.shape[1] < 1:
+            raise ValueError("samples must have shape (B, max_iterations, 3)")
+        if not bool(torch.isfinite(s).all() and torch.isfinite(g).all() and torch.isfinite(smp).all()):
+            raise ValueError("starts, goals and samples must be finite")
+        cub = None if obstacles is None else self._dev(np.asarray(obstacles, dtype=np.float64).reshape(-1, 6), torch.float64)
+        n_obs = 0 if cub is None else int(cub.shape[0])
+        max_iter = int(smp.shape[1])
+        cap = max_iter + 1
+        kw = dict(device=self.device)
+        nodes = torch.empty((B, cap, 3), dtype=torch.float64, **kw)
+        path = torch.empty((B, cap, 3), dtype=torch.float64, **kw)
+        canon = torch.empty((B, cap), dtype=torch.int32, **kw)
+        parent = torch.empty((B, cap), dtype=torch.int32, **kw)
+        best_parent = torch.empty((B, cap), dtype=torch.int32, **kw)
+        counts = torch.empty((B, 6), dtype=torch.int32, **kw)
+        cost = torch.empty((B,), dtype=torch.float64, **kw)
+        self._bind_stream()
+        self.ctx.call("uavac_rrt_star_dev", _ptr(s), _ptr(g), B, float(max_distance), max_iter, _ptr(smp),
+                      _ptr(cub) if n_obs else None, n_obs, _ptr(nodes), _ptr(canon), _ptr(parent), _ptr(best_parent),
+                      _ptr(path), _ptr(counts), _ptr(cost))
+        return RRTDeviceBatch(nodes, canon, parent, best_parent, path, counts, cost)
 
     # -- control ----------------------------------------------------------------
     def fleet(self, plan: Plan, vehicle: Optional[nat.Vehicle] = None, hover: bool = True,
