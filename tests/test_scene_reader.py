@@ -72,3 +72,15 @@ def test_config_helpers_like_the_reference():
     parser = configparser.ConfigParser()
     parser.read_string("[S]\nlimits = [[0, 0, 0], [10, 10, 10]]\n")
     assert np.array_equal(utils.parse_array(parser["S"], "limits"), np.array([[0, 0, 0], [10, 10, 10]]))
+
+
+def test_default_scene_is_the_lab_course():
+    """MujocoSimulation() without a path reads the packaged scene: same data as the test fixture."""
+    from uav_ac.simulation.mujoco_sim import DEFAULT_SCENE_PATH, MujocoSimulation
+    a, b = MujocoSimulation(), MujocoSimulation(SCENE)
+    assert os.path.exists(DEFAULT_SCENE_PATH)
+    assert np.array_equal(a.mission_waypoints, b.mission_waypoints) and np.array_equal(a.obstacles, b.obstacles)
+    assert np.array_equal(a.space_limits, b.space_limits) and a.quad.m == b.quad.m
+    assert a.has_collision is False and a.collision_detected is False
+    a.quad.X[0:3] = [4.0, 7.0, -3.1]                        # the centre of obstacle_00
+    assert a.has_collision is True

@@ -143,9 +143,8 @@ def fly_mission(model_path, velocity: float = 3.0, frequency: int = 10, min_dist
 
 def main(model_path=None) -> None:
     import sys
-    path = model_path or (sys.argv[1] if len(sys.argv) > 1 else None)
-    if path is None:
-        raise SystemExit("usage: python -m uav_ac.main <scene.xml>")
+    from .simulation.mujoco_sim import DEFAULT_SCENE_PATH
+    path = model_path or (sys.argv[1] if len(sys.argv) > 1 else DEFAULT_SCENE_PATH)
     from . import utils
     cfg, cfg_flight = utils.get_config()                     # reference main.py:88-93
     out = fly_mission(path, velocity=cfg_flight.getfloat("velocity"), frequency=cfg.getint("frequency"),

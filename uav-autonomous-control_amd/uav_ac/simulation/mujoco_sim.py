@@ -56,10 +56,13 @@ def _floats(text, n=None, what="attribute"):
     return vals
 
 
+DEFAULT_SCENE_PATH = Path(__file__).parent / "models" / "lab_course.xml"
+
+
 class MujocoSimulation:
     """Scene data + free-flight vehicle.  Same attribute names as the reference adapter."""
 
-    def __init__(self, model_path: str | Path):
+    def __init__(self, model_path: str | Path = DEFAULT_SCENE_PATH):
         root = ET.parse(str(model_path)).getroot()
         world = root.find("worldbody")
         if world is None:
@@ -130,6 +133,8 @@ class MujocoSimulation:
             obstacles.append([c[0] - h[0], c[0] + h[0], c[1] - h[1], c[1] + h[1], c[2] - h[2], c[2] + h[2]])
         self.obstacles = np.asarray(obstacles, dtype=float).reshape(-1, 6)
         self._collision_detected = False
+        if self.has_collision:
+            raise ValueError("quadrotor starts in collision")
 
     def _numeric(self, name: str, expected_size: int) -> np.ndarray:
         if name not in self._numerics:
@@ -137,6 +142,14 @@ class MujocoSimulation:
         if len(self._numerics[name]) != expected_size:
             raise ValueError(f"MuJoCo numeric '{name}' must contain {expected_size} values")
         return self._numerics[name].copy()
+
+    @property
+    def has_collision(self) -> bool:
+        """The vehicle's position is inside a planning obstacle right now (the reference asks MuJoCo for contacts,
+        mujoco_sim.py:93-96; free flight has no ground and no body geometry, so this is the position test)."""
+        p, o = self.quad.position, self.obstacles
+        return bool(len(o)) and bool(np.any((p[0] >= o[:, 0]) & (p[0] <= o[:, 1]) & (p[1] >= o[:, 2]) & (p[1] <= o[:, 3]) &
+                                            (p[2] >= o[:, 4]) & (p[2] <= o[:, 5])))
 
     @property
     def collision_detected(self) -> bool:
