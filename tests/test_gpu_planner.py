@@ -1,6 +1,5 @@
 """GPU parity of the HIP planner (K0 row counts, K1 solve, K2 sampler + yaw scan) against the
 reference's golden vectors and the CPU oracle.  Everything goes through the C ABI (ctypes)."""
-import ctypes as C
 
 import numpy as np
 import pytest

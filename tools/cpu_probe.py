@@ -1,4 +1,4 @@
-import os, sys
+import sys
 sys.path.insert(0, '.')
 from oracle import c_oracle as co
 from oracle.cpu_baseline import effective_cpus
