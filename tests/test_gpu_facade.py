@@ -214,3 +214,17 @@ def test_lab_mission_from_scene_meets_reference_integration_bounds():
     assert out["distance_to_goal"] < 0.5 and out["goal_reached"]
     assert out["mean_tracking_error"] < 0.5
     assert out["collision_detected"] is False
+
+
+def test_end_to_end_example_runs():
+    """examples/plan_and_fly.py: RRT* -> thinning -> obstacle-aware minimum snap -> fused flight, 64 vehicles."""
+    import importlib.util
+    import os
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("plan_and_fly", os.path.join(REPO, "examples", "plan_and_fly.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(64)
+    assert out["found"] >= 60
+    assert out["arrived"] >= 0.9 * out["flown"]
+    assert out["collided"] <= 0.05 * out["flown"]

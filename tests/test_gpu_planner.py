@@ -347,6 +347,47 @@ def test_batched_obstacle_replan_matches_reference_and_oracle(eng):
     assert len(lenient.final_waypoints[1]) - 1 <= 64 and len(lenient.mission(1)) > 0
 
 
+def test_recheck_passes_leave_no_row_inside_any_obstacle(eng):
+    """Beyond the reference (which never re-checks an earlier obstacle): with recheck_passes the final rows of every
+    converged mission are outside EVERY cuboid; without it the same missions show the reference's leftover conflicts
+    or none -- never more rows than the re-checked plan fixes."""
+    g = load_golden("fixed_missions.npz")
+    aabbs = g["lab_aabbs"] if "lab_aabbs" in g.files else None
+    if aabbs is None:
+        aabbs = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0],
+                          [13.3, 14.7, 6.3, 7.7, -6.0, 0.0], [20.2, 20.8, 4.0, 10.0, -3.3, -2.7]])
+    # long-legged courses that hug obstacle corners: thinned RRT* paths across the lab (deterministic seeds)
+    from uav_ac.planning.rrt import RRTStar, draw_random_nodes_batch
+    rng = np.random.default_rng(31)
+    n = 128
+    lw, up = np.array([0.0, 0.0, -6.0]), np.array([24.0, 14.0, 0.0])
+    starts = np.round(np.array([1.0, 7.0, -1.3]) + rng.uniform(-0.5, 0.5, (n, 3)) * [1, 4, 0.5], 2)
+    goals = np.round(np.array([23.0, 7.0, -2.0]) + rng.uniform(-0.5, 0.5, (n, 3)) * [1, 4, 0.5], 2)
+    found = eng.rrt_star(starts, goals, 1.5, draw_random_nodes_batch(np.arange(n), lw, up, goals, 1200), aabbs).to_host()
+    thin = RRTStar(np.stack([lw, up]), starts[0], goals[0], 1.5, 1, aabbs)
+    missions = [thin.simplify_path(found.path(b)) for b in np.flatnonzero(found.status == 0)]
+    assert len(missions) >= 100
+
+    def rows_inside(rp):
+        bad = np.zeros(rp.B, dtype=int)
+        for b in range(rp.B):
+            p = rp.mission(b)[:, :3]
+            for c in aabbs:
+                bad[b] += int(np.sum((p[:, 0] >= c[0]) & (p[:, 0] <= c[1]) & (p[:, 1] >= c[2]) & (p[:, 1] <= c[3]) &
+                                     (p[:, 2] >= c[4]) & (p[:, 2] <= c[5])))
+        return bad
+    once = eng.plan_collision_free(missions, aabbs, 2.0, 0.01, strict=False)
+    again = eng.plan_collision_free(missions, aabbs, 2.0, 0.01, strict=False, recheck_passes=6)
+    left_once, left_again = rows_inside(once), rows_inside(again)
+    assert again.converged.sum() >= 0.6 * len(missions)
+    assert (left_once > 0).sum() >= 1                       # the reference's single pass does leave conflicts here
+    assert not left_again[again.converged].any()
+    assert left_once.sum() >= left_again.sum()
+    same = [b for b in range(len(missions)) if left_once[b] == 0 and once.converged[b]]
+    for b in same[:20]:                                     # nothing to fix => the extra passes change nothing
+        assert np.array_equal(once.final_waypoints[b], again.final_waypoints[b])
+
+
 def test_randomised_shapes_velocities_and_steps(eng):
     """40 random (B, m, leg lengths, velocity, dt) draws against the oracle's exact KKT path: row counts and
     spline ids exact, samples <= 1e-7."""

@@ -145,7 +145,7 @@ class Engine:
         return plan
 
     def plan_collision_free(self, waypoints, obstacles, velocity: float = 1.0, dt: float = 0.01,
-                            max_iterations: int = 64, strict: bool = True) -> RaggedPlan:
+                            max_iterations: int = 64, strict: bool = True, recheck_passes: int = 0) -> RaggedPlan:
         """Batched `MinimumSnap(path, obstacles, velocity, dt).get_trajectory()` with obstacles
         (minimum_snap.py:63-95) for B missions at once.
 
@@ -158,6 +158,9 @@ class Engine:
         not: it cannot end when a waypoint lies inside a cuboid, or when a leg crosses one squarely).  A mission
         that exhausts `max_iterations` or UAVAC_MAX_SEGMENTS raises RuntimeError when `strict`; otherwise it is
         reported in `RaggedPlan.converged` (False) with its last (still colliding) trajectory and the batch goes on.
+        `recheck_passes` > 0 goes beyond the reference: missions that received midpoints are swept over the whole
+        obstacle list again (up to that many extra passes, until a pass inserts nothing), which removes the
+        conflicts a late midpoint can create with an earlier obstacle.
         """
         torch = self._torch
         wps = [np.ascontiguousarray(w, dtype=np.float64) for w in waypoints]
@@ -197,16 +200,23 @@ class Engine:
 
         if len(cuboids) == 0:
             run_round(list(range(B)), None)
-        for cub in cuboids:
-            active = [b for b in range(B) if b not in failed]
-            for _ in range(max_iterations + 1):
-                if not active:
-                    break
-                active = run_round(active, cub)
-            else:
-                if strict:
-                    raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
-                failed.update(active)
+        todo = list(range(B))                                  # missions the next pass over the obstacles looks at
+        for sweep in range(1 + max(0, int(recheck_passes))):
+            touched = set()
+            for cub in cuboids:
+                active = [b for b in todo if b not in failed]
+                for it in range(max_iterations + 1):
+                    if not active:
+                        break
+                    active = run_round(active, cub)
+                    touched.update(active)
+                else:
+                    if strict:
+                        raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
+                    failed.update(active)
+            todo = sorted(touched - failed)                     # only missions that changed can have new conflicts
+            if not todo:
+                break
 
         # stitch the final trajectories together in mission order
         nrows = torch.zeros((B,), dtype=torch.int64, device=self.device)
