@@ -255,6 +255,13 @@ int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p
                                int p1_is_single, int E, double *out);
 int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, int p1_is_single,
                            int E, double *out);
+/* RRTStar.simplify_path (rrt.py:93-116) for B paths at once: paths[B][cap][3] with lens[B] waypoints
+ * each (e.g. best_path / counts[4] of uavac_rrt_star) -> out_paths[B][cap][3], out_lens[B]: from
+ * each kept waypoint the farthest one with a clear direct connection is kept next. */
+int uavac_rrt_simplify_dev(uavac_ctx *ctx, const double *paths, const int32_t *lens, int B, int cap,
+                           const double *cuboids, int n_obs, double *out_paths, int32_t *out_lens);
+int uavac_rrt_simplify(uavac_ctx *ctx, const double *paths, const int32_t *lens, int B, int cap,
+                       const double *cuboids, int n_obs, double *out_paths, int32_t *out_lens);
 /* RRTStar.path_cost (rrt.py:84-91): the edge lengths of the polyline path[n][3] summed in path
  * order (also the accumulation of _cost_to_come, :163-173, on the node -> start chain). */
 int uavac_rrt_path_cost_dev(uavac_ctx *ctx, const double *path, int n, double *cost);

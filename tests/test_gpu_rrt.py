@@ -158,6 +158,45 @@ def test_device_resident_entry_point_equals_host_twin():
     assert (host.status == 0).sum() > B // 4
 
 
+def test_batched_simplify_matches_reference_and_facade():
+    """Engine.rrt_simplify (one wavefront per path) == the reference's simplify_path of its own best paths (goldens),
+    and == the facade's host loop on a batch of fresh problems."""
+    from uav_ac.fleet import Engine
+    from uav_ac.planning.rrt import RRTStar, draw_random_nodes_batch
+    eng = Engine("cuda:0")
+    for name in RUNS:
+        g = load(name)
+        if str(g["error"]):
+            continue
+        obstacles = g["obstacles"] if len(g["obstacles"]) else None
+        res = eng.rrt_star(g["start"][None], g["goal"][None], float(g["step"]), padded(g)[None], obstacles)
+        paths, lens = eng.rrt_simplify(res, obstacles)
+        n = int(lens[0])
+        assert np.array_equal(paths[0, :n].cpu().numpy(), g["simplified_path"]), name
+        assert not paths[0, n:].any()
+    rng = np.random.default_rng(12)
+    B, max_iter = 96, 900
+    lw, up = np.array([0.0, 0.0, -6.0]), np.array([24.0, 14.0, 0.0])
+    obstacles = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0],
+                          [13.3, 14.7, 6.3, 7.7, -6.0, 0.0], [20.2, 20.8, 4.0, 10.0, -3.3, -2.7]])
+    starts = np.round(rng.uniform([0.5, 1, -3], [2, 13, -1], (B, 3)), 2)
+    goals = np.round(rng.uniform([22, 1, -3], [23.5, 13, -1], (B, 3)), 2)
+    res = eng.rrt_star(starts, goals, 1.5, draw_random_nodes_batch(np.arange(B), lw, up, goals, max_iter), obstacles)
+    paths, lens = eng.rrt_simplify(res, obstacles)
+    host = res.to_host()
+    helper = RRTStar(np.stack([lw, up]), starts[0], goals[0], 1.5, 1, obstacles)
+    shorter = 0
+    for b in range(B):
+        n = int(lens[b])
+        if host.status[b] != 0:
+            assert n == 0
+            continue
+        ref = helper.simplify_path(host.path(b))
+        assert np.array_equal(paths[b, :n].cpu().numpy(), ref)
+        shorter += n < host.best_len[b]
+    assert shorter > B // 2
+
+
 def test_large_tree_takes_the_scratch_path():
     """max_iterations too large for LDS (52 B per node > 160 KB): the same kernel on HBM scratch, same results."""
     from oracle import c_oracle as co

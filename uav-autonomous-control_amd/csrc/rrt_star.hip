@@ -444,6 +444,42 @@ __global__ void rrt_edge_lengths_kernel(const double *__restrict__ p0, const dou
     out[e] = norm3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
 }
 
+// RRTStar.simplify_path (rrt.py:93-116) for B paths, one wavefront each: from the current waypoint the lanes test the
+// direct connection to the last, second-to-last, ... waypoint at once; the farthest clear one is the next waypoint.
+__global__ void __launch_bounds__(W)
+rrt_simplify_kernel(const double *__restrict__ paths, const int32_t *__restrict__ lens, int cap,
+                    const double *__restrict__ cuboids, int n_obs, double *__restrict__ out, int32_t *__restrict__ out_lens) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double *path = paths + (size_t)b * cap * 3;
+    double *dst = out + (size_t)b * cap * 3;
+    const int L = lens[b];
+    int n_out = 0;
+    if (L <= 2) {
+        for (int i = lane; i < 3 * L; i += W) dst[i] = path[i];
+        n_out = L > 0 ? L : 0;
+    } else {
+        int cur = 0;
+        if (lane == 0) { dst[0] = path[0]; dst[1] = path[1]; dst[2] = path[2]; }
+        n_out = 1;
+        while (cur < L - 1) {
+            const double a0 = path[3 * cur], a1 = path[3 * cur + 1], a2 = path[3 * cur + 2];
+            int next = cur + 1;
+            for (int top = L - 1; top > cur + 1; top -= W) {
+                const int j = top - lane;
+                bool clear = false;
+                if (j > cur + 1) clear = valid_connection(a0, a1, a2, path[3 * j], path[3 * j + 1], path[3 * j + 2], cuboids, n_obs);
+                const unsigned long long m = __ballot(clear);
+                if (m) { next = top - first_lane(m); break; }
+            }
+            if (lane == 0) { dst[3 * n_out] = path[3 * next]; dst[3 * n_out + 1] = path[3 * next + 1]; dst[3 * n_out + 2] = path[3 * next + 2]; }
+            ++n_out;
+            cur = next;
+        }
+    }
+    for (int i = 3 * n_out + lane; i < 3 * cap; i += W) dst[i] = 0.0;
+    if (lane == 0) out_lens[b] = n_out;
+}
+
 // RRTStar.path_cost (rrt.py:84-91): edge lengths of the polyline summed in order (one lane: the order is the result)
 __global__ void rrt_path_cost_kernel(const double *__restrict__ path, int n, double *__restrict__ out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -553,6 +589,17 @@ int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p
     return UAVAC_OK;
 }
 
+int uavac_rrt_simplify_dev(uavac_ctx *ctx, const double *paths, const int32_t *lens, int B, int cap, const double *cuboids,
+                           int n_obs, double *out_paths, int32_t *out_lens) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (B < 1 || cap < 1 || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "B and cap must be >= 1");
+    if (!paths || !lens || !out_paths || !out_lens || (n_obs > 0 && !cuboids)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    hipLaunchKernelGGL(rrt_simplify_kernel, dim3(B), dim3(W), 0, ctx->stream, paths, lens, cap, cuboids, n_obs, out_paths,
+                       out_lens);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
 int uavac_rrt_path_cost_dev(uavac_ctx *ctx, const double *path, int n, double *cost) {
     if (!ctx) return UAVAC_EINVAL;
     if (n < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
@@ -653,6 +700,31 @@ int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, i
     if (int rc = uavac_rrt_edge_lengths_dev(ctx, d0.as<double>(), d1.as<double>(), p1_is_single, E, dout.as<double>()))
         return rc;
     UAVAC_HIP(ctx, hipMemcpyAsync(out, dout.p, 8 * zE, hipMemcpyDeviceToHost, ctx->stream));
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UAVAC_OK;
+}
+
+int uavac_rrt_simplify(uavac_ctx *ctx, const double *paths, const int32_t *lens, int B, int cap, const double *cuboids,
+                       int n_obs, double *out_paths, int32_t *out_lens) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (B < 1 || cap < 1 || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "B and cap must be >= 1");
+    if (!paths || !lens || !out_paths || !out_lens || (n_obs > 0 && !cuboids)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    for (int b = 0; b < B; ++b)
+        if (lens[b] < 0 || lens[b] > cap) return uavac_fail(ctx, UAVAC_EINVAL, "path length outside [0, cap]");
+    const size_t np = (size_t)B * cap * 3;
+    DevBuf dp, dl, dc, dout, dol;
+    UAVAC_HIP(ctx, dp.alloc(8 * np));
+    UAVAC_HIP(ctx, dl.alloc(4 * (size_t)B));
+    UAVAC_HIP(ctx, dc.alloc(48 * (size_t)n_obs));
+    UAVAC_HIP(ctx, dout.alloc(8 * np));
+    UAVAC_HIP(ctx, dol.alloc(4 * (size_t)B));
+    UAVAC_HIP(ctx, hipMemcpyAsync(dp.p, paths, 8 * np, hipMemcpyHostToDevice, ctx->stream));
+    UAVAC_HIP(ctx, hipMemcpyAsync(dl.p, lens, 4 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+    if (n_obs > 0) UAVAC_HIP(ctx, hipMemcpyAsync(dc.p, cuboids, 48 * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = uavac_rrt_simplify_dev(ctx, dp.as<double>(), dl.as<int32_t>(), B, cap, n_obs > 0 ? dc.as<double>() : nullptr,
+                                        n_obs, dout.as<double>(), dol.as<int32_t>())) return rc;
+    UAVAC_HIP(ctx, hipMemcpyAsync(out_paths, dout.p, 8 * np, hipMemcpyDeviceToHost, ctx->stream));
+    UAVAC_HIP(ctx, hipMemcpyAsync(out_lens, dol.p, 4 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }

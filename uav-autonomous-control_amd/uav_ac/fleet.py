@@ -326,6 +326,21 @@ class Engine:
                       _ptr(path), _ptr(counts), _ptr(cost))
         return RRTDeviceBatch(nodes, canon, parent, best_parent, path, counts, cost)
 
+    def rrt_simplify(self, batch: "RRTDeviceBatch", obstacles=None):
+        """`RRTStar.simplify_path` (rrt.py:93-116) of every best path of `batch` in one launch.
+        -> (paths (B, cap, 3), lengths (B,)) on the GPU; rows past a path's length are zero."""
+        torch = self._torch
+        B, cap = int(batch.best_path.shape[0]), int(batch.best_path.shape[1])
+        cub = None if obstacles is None else self._dev(np.asarray(obstacles, dtype=np.float64).reshape(-1, 6), torch.float64)
+        n_obs = 0 if cub is None else int(cub.shape[0])
+        lens = batch.counts[:, 4].contiguous()
+        out = torch.empty_like(batch.best_path)
+        out_lens = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._bind_stream()
+        self.ctx.call("uavac_rrt_simplify_dev", _ptr(batch.best_path), _ptr(lens), B, cap, _ptr(cub) if n_obs else None, n_obs,
+                      _ptr(out), _ptr(out_lens))
+        return out, out_lens
+
     # -- control ----------------------------------------------------------------
     def fleet(self, plan: Plan, vehicle: Optional[nat.Vehicle] = None, hover: bool = True,
               positions=None) -> "Fleet":
