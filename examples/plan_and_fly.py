@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End to end on one GPU: B vehicles cross the laboratory course.
 
-  1. RRT* finds a collision-free polyline per vehicle          (Engine.rrt_star, one wavefront per problem)
+  1. RRT* finds a collision-free polyline per vehicle          (Engine.rrt_star_seeded: node draws + planner, a wavefront per problem)
   2. its waypoints are thinned                                  (Engine.rrt_simplify, one wavefront per path)
   3. minimum-snap trajectories are planned around the obstacles (Engine.plan_collision_free, batched re-plan loop)
   4. the cascaded controller flies them, with the per-tick obstacle test fused into the rollout
@@ -20,7 +20,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "uav-autonomous-control_amd")]
 
 from uav_ac.fleet import Engine                                   # noqa: E402
-from uav_ac.planning.rrt import draw_random_nodes_batch           # noqa: E402
 from uav_ac.simulation.mujoco_sim import MujocoSimulation         # noqa: E402
 
 
@@ -35,8 +34,7 @@ def main(B: int = 256, velocity: float = 2.0, seed: int = 0, clearance: float = 
     goals = np.round(np.array([23.0, 7.0, -2.0]) + rng.uniform(-0.5, 0.5, (B, 3)) * [1, 4, 0.5], 2)
     eng = Engine()
     t0 = time.perf_counter()
-    samples = draw_random_nodes_batch(seed + np.arange(B), lw, up, goals, 1500)
-    found = eng.rrt_star(starts, goals, 1.5, samples, keep_out)
+    found = eng.rrt_star_seeded(starts, goals, np.stack([lw, up]), seed + np.arange(B), 1.5, 1500, keep_out)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     thin, thin_len = eng.rrt_simplify(found, keep_out)

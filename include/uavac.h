@@ -255,6 +255,14 @@ int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p
                                int p1_is_single, int E, double *out);
 int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, int p1_is_single,
                            int E, double *out);
+/* The nodes RRTStar._generate_random_node (rrt.py:118-127) returns in n consecutive calls after
+ * np.random.seed(seeds[b]) -- NumPy's legacy MT19937 stream reproduced on the GPU, bit for bit --
+ * for B problems: samples[B][n][3] (what uavac_rrt_star takes); consumed[B][n] (or NULL) = doubles
+ * of the stream used up to and including draw i.  limits_lw / limits_up are HOST pointers to 3
+ * doubles (the space limits shared by the batch); goals[B][3] must already be rounded to 0.01. */
+int uavac_rrt_draw_nodes_dev(uavac_ctx *ctx, const uint32_t *seeds, const double *goals, int B, int n,
+                             const double *limits_lw, const double *limits_up, double epsilon,
+                             double *samples, int64_t *consumed);
 /* RRTStar.simplify_path (rrt.py:93-116) for B paths at once: paths[B][cap][3] with lens[B] waypoints
  * each (e.g. best_path / counts[4] of uavac_rrt_star) -> out_paths[B][cap][3], out_lens[B]: from
  * each kept waypoint the farthest one with a clear direct connection is kept next. */

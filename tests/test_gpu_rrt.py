@@ -158,6 +158,29 @@ def test_device_resident_entry_point_equals_host_twin():
     assert (host.status == 0).sum() > B // 4
 
 
+def test_gpu_node_drawing_is_numpys_stream():
+    """Engine.rrt_draw_nodes == 2 000 calls of the reference's _generate_random_node after np.random.seed (golden), and
+    == the host replay of NumPy's generator for many seeds, including seeds that differ in the top bit and runs
+    long enough to regenerate the MT19937 state dozens of times; `consumed` counts the stream's doubles."""
+    from uav_ac.fleet import Engine
+    from uav_ac.planning.rrt import draw_random_nodes, draw_random_nodes_batch
+    eng = Engine("cuda:0")
+    g = load("rrt_draws")
+    got = eng.rrt_draw_nodes([int(g["seed"])], g["goal"][None], g["limits"][0], g["limits"][1], len(g["nodes"]))
+    assert np.array_equal(got[0].cpu().numpy(), g["nodes"])
+    seeds = np.array([0, 1, 2, 12345, 2**31 - 1, 2**31, 2**32 - 1, 987654321] + list(range(100, 164)))
+    rng = np.random.default_rng(4)
+    lw, up = np.array([-3.0, 0.5, -6.0]), np.array([24.0, 14.25, 0.0])
+    goals = np.round(rng.uniform(lw, up, (len(seeds), 3)), 2)
+    n = 5000
+    samples, consumed = eng.rrt_draw_nodes(seeds, goals, lw, up, n, with_consumed=True)
+    assert np.array_equal(samples.cpu().numpy(), draw_random_nodes_batch(seeds, lw, up, goals, n))
+    ref_nodes, ref_consumed = draw_random_nodes(np.random.RandomState(int(seeds[3])).random_sample, lw, up, goals[3], n)
+    assert np.array_equal(consumed[3].cpu().numpy(), ref_consumed)
+    other = eng.rrt_draw_nodes(seeds[:4], goals[:4], lw, up, 300, epsilon=0.5)
+    assert np.array_equal(other.cpu().numpy(), draw_random_nodes_batch(seeds[:4], lw, up, goals[:4], 300, epsilon=0.5))
+
+
 def test_batched_simplify_matches_reference_and_facade():
     """Engine.rrt_simplify (one wavefront per path) == the reference's simplify_path of its own best paths (goldens),
     and == the facade's host loop on a batch of fresh problems."""

@@ -20,11 +20,16 @@ starts = np.round(rng.uniform([0.5, 1, -3], [2, 13, -1], (Bmax, 3)), 2)
 goals = np.round(rng.uniform([22, 1, -3], [23.5, 13, -1], (Bmax, 3)), 2)
 t0 = time.perf_counter()
 samples = draw_random_nodes_batch(np.arange(Bmax), lw, up, goals, max_iter)
-print(f"host: drew {Bmax} x {max_iter} nodes in {time.perf_counter() - t0:.1f} s")
+print(f"host (NumPy replay): drew {Bmax} x {max_iter} nodes in {time.perf_counter() - t0:.2f} s")
 
 from uav_ac.fleet import Engine
 eng = Engine("cuda:0")
 dev = eng.device
+eng.rrt_draw_nodes(np.arange(64), goals[:64], lw, up, max_iter); torch.cuda.synchronize()
+a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+a.record(); on_gpu = eng.rrt_draw_nodes(np.arange(Bmax), goals, lw, up, max_iter); b.record(); torch.cuda.synchronize()
+print(f"GPU (MT19937 kernel): drew {Bmax} x {max_iter} nodes in {a.elapsed_time(b):.2f} ms, "
+      f"identical to the host replay: {bool((on_gpu.cpu().numpy() == samples).all())}")
 for B in Bs:
     s_, g_, smp = (torch.as_tensor(x[:B], device=dev) for x in (starts, goals, samples))
     eng.rrt_star(s_, g_, step, smp, LAB); torch.cuda.synchronize()

@@ -444,6 +444,89 @@ __global__ void rrt_edge_lengths_kernel(const double *__restrict__ p0, const dou
     out[e] = norm3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
 }
 
+// The node sequence RRTStar._generate_random_node (rrt.py:118-127) produces after np.random.seed(seed), drawn on the
+// GPU: NumPy's legacy generator is MT19937 seeded by init_genrand (integer seeds), random_sample() is the 53-bit
+// double built from two outputs, uniform(lo, hi) = lo + (hi - lo) * random_sample(), np.round(x, 2) = rint(100 x) / 100.
+// One wavefront per problem: the 64 lanes regenerate the 624-word state together (the three dependency-free
+// ranges of the recurrence), temper and pair the words into 312 doubles in LDS, and every lane then walks the
+// stream in step (one double for the goal bias, three more unless the goal was drawn) -- uniform control flow, lane 0
+// writes.  All integer / exactly rounded arithmetic: the result is NumPy's, bit for bit.
+__device__ __forceinline__ unsigned mt_mix(unsigned u, unsigned v, unsigned far) {
+    const unsigned y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__global__ void __launch_bounds__(W)
+rrt_draw_nodes_kernel(const unsigned *__restrict__ seeds, const double *__restrict__ goals, int B, int n, double lw0,
+                      double lw1, double lw2, double up0, double up1, double up2, double epsilon,
+                      double *__restrict__ samples, int64_t *__restrict__ consumed) {
+    __shared__ unsigned mt[624];
+    __shared__ double dbl[312];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    // init_genrand: sequential by nature (lane 0), 624 steps once per problem
+    if (lane == 0) {
+        unsigned sd = seeds[b];
+        for (int i = 0; i < 624; ++i) { mt[i] = sd; sd = 1812433253u * (sd ^ (sd >> 30)) + (unsigned)i + 1u; }
+    }
+    __syncthreads();
+    const double g0 = goals[3 * b], g1 = goals[3 * b + 1], g2 = goals[3 * b + 2];
+    const double r0 = up0 - lw0, r1 = up1 - lw1, r2 = up2 - lw2;
+    double *out = samples + (size_t)b * n * 3;
+    int64_t *cons = consumed ? consumed + (size_t)b * n : nullptr;
+    int pos = 312;                                   // doubles of the current block already used (312 = none left)
+    int64_t used = 0;
+    auto refill = [&]() {
+        // new[i] = old[i+397] ^ f(old[i], old[i+1]) for i < 227; new[i] = new[i-227] ^ f(old[i], old[i+1]) beyond
+        for (int base = 0; base < 227; base += W) {
+            const int i = base + lane;
+            unsigned v = 0;
+            if (i < 227) v = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
+            __syncthreads();
+            if (i < 227) mt[i] = v;
+            __syncthreads();
+        }
+        for (int lo = 227; lo < 623; lo += 227) {                     // [227, 454), [454, 623): each reads the range before it
+            const int hi = lo + 227 < 623 ? lo + 227 : 623;
+            for (int base = lo; base < hi; base += W) {
+                const int i = base + lane;
+                unsigned v = 0;
+                if (i < hi) v = mt_mix(mt[i], mt[i + 1], mt[i - 227]);
+                __syncthreads();
+                if (i < hi) mt[i] = v;
+                __syncthreads();
+            }
+        }
+        if (lane == 0) mt[623] = mt_mix(mt[623], mt[0], mt[396]);
+        __syncthreads();
+        for (int k = lane; k < 312; k += W) {                         // genrand_res53 on tempered pairs
+            unsigned a = mt[2 * k], c = mt[2 * k + 1];
+            a ^= a >> 11; a ^= (a << 7) & 0x9d2c5680u; a ^= (a << 15) & 0xefc60000u; a ^= a >> 18;
+            c ^= c >> 11; c ^= (c << 7) & 0x9d2c5680u; c ^= (c << 15) & 0xefc60000u; c ^= c >> 18;
+            dbl[k] = ((double)(a >> 5) * 67108864.0 + (double)(c >> 6)) / 9007199254740992.0;
+        }
+        __syncthreads();
+        pos = 0;
+    };
+    auto next = [&]() {
+        if (pos >= 312) refill();
+        ++used;
+        return dbl[pos++];
+    };
+    for (int it = 0; it < n; ++it) {
+        const double u = next();
+        double x = g0, y = g1, z = g2;
+        if (!(0.0 + (1.0 - 0.0) * u < epsilon)) {
+            x = round2(lw0 + r0 * next());
+            y = round2(lw1 + r1 * next());
+            z = round2(lw2 + r2 * next());
+        }
+        if (lane == 0) {
+            out[3 * it] = x; out[3 * it + 1] = y; out[3 * it + 2] = z;
+            if (cons) cons[it] = used;
+        }
+    }
+}
+
 // RRTStar.simplify_path (rrt.py:93-116) for B paths, one wavefront each: from the current waypoint the lanes test the
 // direct connection to the last, second-to-last, ... waypoint at once; the farthest clear one is the next waypoint.
 __global__ void __launch_bounds__(W)
@@ -585,6 +668,22 @@ int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p
     if (!p0 || !p1 || !out) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     hipLaunchKernelGGL(rrt_edge_lengths_kernel, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, p0, p1,
                        p1_is_single ? 0 : 3, E, out);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
+int uavac_rrt_draw_nodes_dev(uavac_ctx *ctx, const uint32_t *seeds, const double *goals, int B, int n,
+                             const double *limits_lw_host, const double *limits_up_host, double epsilon, double *samples,
+                             int64_t *consumed) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (B < 1 || n < 1) return uavac_fail(ctx, UAVAC_EINVAL, "B and n must be >= 1");
+    if (!seeds || !goals || !limits_lw_host || !limits_up_host || !samples) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    for (int a = 0; a < 3; ++a)
+        if (!std::isfinite(limits_lw_host[a]) || !std::isfinite(limits_up_host[a]))
+            return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite space limit");
+    hipLaunchKernelGGL(rrt_draw_nodes_kernel, dim3(B), dim3(W), 0, ctx->stream, seeds, goals, B, n, limits_lw_host[0],
+                       limits_lw_host[1], limits_lw_host[2], limits_up_host[0], limits_up_host[1], limits_up_host[2], epsilon,
+                       samples, consumed);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

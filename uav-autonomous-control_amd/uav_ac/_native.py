@@ -83,6 +83,7 @@ _SIGNATURES = {
     "uavac_rrt_segment_hits": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P]),
     "uavac_rrt_edge_lengths_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "uavac_rrt_edge_lengths": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "uavac_rrt_draw_nodes_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_double, _P, _P]),
     "uavac_rrt_simplify_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "uavac_rrt_simplify": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "uavac_rrt_path_cost_dev": (C.c_int, [_P, _P, C.c_int, _P]),

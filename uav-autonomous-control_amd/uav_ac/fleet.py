@@ -326,6 +326,34 @@ class Engine:
                       _ptr(path), _ptr(counts), _ptr(cost))
         return RRTDeviceBatch(nodes, canon, parent, best_parent, path, counts, cost)
 
+    def rrt_draw_nodes(self, seeds, goals, limits_lw, limits_up, n: int, epsilon: float = 0.15, with_consumed: bool = False):
+        """What `RRTStar._generate_random_node` returns in `n` calls after `np.random.seed(seeds[b])`, for B problems,
+        generated on the GPU (NumPy's legacy MT19937 stream, bit for bit) -> samples (B, n, 3) [, consumed (B, n)]."""
+        torch = self._torch
+        g = self._dev(np.round(np.asarray(goals.cpu() if isinstance(goals, torch.Tensor) else goals, dtype=np.float64), 2),
+                      torch.float64)
+        B = int(g.shape[0])
+        sd = np.asarray(seeds, dtype=np.int64).reshape(-1)
+        if len(sd) != B or sd.min() < 0 or sd.max() > 0xffffffff:
+            raise ValueError("one seed in [0, 2**32) per problem")
+        sd_t = torch.as_tensor(sd.astype(np.uint32).view(np.int32), device=self.device)
+        lw = np.ascontiguousarray(limits_lw, dtype=np.float64)[:3].copy()
+        up = np.ascontiguousarray(limits_up, dtype=np.float64)[:3].copy()
+        samples = torch.empty((B, int(n), 3), dtype=torch.float64, device=self.device)
+        consumed = torch.empty((B, int(n)), dtype=torch.int64, device=self.device) if with_consumed else None
+        self._bind_stream()
+        self.ctx.call("uavac_rrt_draw_nodes_dev", _ptr(sd_t), _ptr(g), B, int(n), nat.np_ptr(lw), nat.np_ptr(up), float(epsilon),
+                      _ptr(samples), _ptr(consumed))
+        return (samples, consumed) if with_consumed else samples
+
+    def rrt_star_seeded(self, starts, goals, space_limits, seeds, max_distance: float, max_iterations: int, obstacles=None,
+                        epsilon: float = 0.15) -> "RRTDeviceBatch":
+        """B runs of `np.random.seed(seeds[b]); RRTStar(space_limits, starts[b], goals[b], max_distance, max_iterations,
+        obstacles).run()` entirely on the GPU: the node draws (`rrt_draw_nodes`) and the planner (`rrt_star`)."""
+        goals = np.round(np.asarray(goals, dtype=np.float64), 2)
+        samples = self.rrt_draw_nodes(seeds, goals, space_limits[0], space_limits[1], max_iterations, epsilon)
+        return self.rrt_star(starts, goals, max_distance, samples, obstacles)
+
     def rrt_simplify(self, batch: "RRTDeviceBatch", obstacles=None):
         """`RRTStar.simplify_path` (rrt.py:93-116) of every best path of `batch` in one launch.
         -> (paths (B, cap, 3), lengths (B,)) on the GPU; rows past a path's length are zero."""
