@@ -5,6 +5,8 @@
 //   2  [K/2][B/64][13][64][2]     two ticks per 16-B lane store: 13 x 1 KB per two ticks
 //   3  [K/4][B/64][13][64][4]     four ticks per lane: 26 x 1 KB per four ticks
 //   4  [B/64][K][13][64]          workgroup-major: every workgroup streams its own contiguous 6.5 KB x K region
+//   5  [K][13][B], XCD-contiguous  layout 0, but the workgroups of one XCD (blockIdx % 8) own one contiguous eighth of
+//                                  every row instead of every eighth 512-B piece
 // Build: hipcc --offload-arch=gfx950 -O3 tools/log_layout_probe.hip -o tools/log_layout_probe.bin 2>/dev/null
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,9 +35,13 @@ __global__ void __launch_bounds__(64) k(double *log, int B, int K) {
                 *(d2 *)(p + lane * 2) = v;                 // 64 lanes x 16 B = first KB of the row's 2 KB
                 *(d2 *)(p + 128 + lane * 2) = v;
             }
-    } else {
+    } else if (MODE == 4) {
         for (int t = 0; t < K; ++t)
             for (int r = 0; r < 13; ++r) log[((g * K + t) * 13 + r) * 64 + lane] = 1.0 + t;
+    } else {
+        const size_t g2 = (g % 8) * (G / 8) + g / 8;
+        for (int t = 0; t < K; ++t)
+            for (int r = 0; r < 13; ++r) log[((size_t)t * 13 + r) * sB + g2 * 64 + lane] = 1.0 + t;
     }
 }
 template <int MODE> void run(double *log, int B, int K, const char *name) {
@@ -56,6 +62,7 @@ int main() {
         run<2>(log, B, K, "[K/2][B/64][13][64][2]");
         run<3>(log, B, K, "[K/4][B/64][13][64][4]");
         run<4>(log, B, K, "[B/64][K][13][64]");
+        run<5>(log, B, K, "[K][13][B] XCD-contiguous");
     }
     return 0;
 }

@@ -6,11 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d2 __attribute__((ext_vector_type(2)));
-template <int CHUNK_ROWS>
+template <int CHUNK_ROWS, int XCD = 0>
 __global__ void __launch_bounds__(64) k(double *traj, int rows_per_mission) {
     constexpr int PAIRS = CHUNK_ROWS * 11 / 2;
     const int lane = threadIdx.x;
-    double *base = traj + (size_t)blockIdx.x * rows_per_mission * 11;
+    // XCD: the workgroups of one XCD (blockIdx % 8) take a contiguous eighth of the missions
+    const size_t mission = XCD ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    double *base = traj + mission * rows_per_mission * 11;
     const int npairs_total = rows_per_mission * 11 / 2;
     for (int c0 = 0; c0 < npairs_total; c0 += PAIRS) {
         for (int p = lane; p < PAIRS && c0 + p < npairs_total; p += 64) {
@@ -19,13 +21,13 @@ __global__ void __launch_bounds__(64) k(double *traj, int rows_per_mission) {
         }
     }
 }
-template <int CHUNK_ROWS> void run(double *traj, int B, int R, const char *what) {
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<CHUNK_ROWS><<<B, 64>>>(traj, R);
-    hipEventRecord(e0);
-    for (int i = 0; i < 5; ++i) k<CHUNK_ROWS><<<B, 64>>>(traj, R);
-    hipEventRecord(e1); hipDeviceSynchronize();
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+template <int CHUNK_ROWS, int XCD = 0> void run(double *traj, int B, int R, const char *what) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<CHUNK_ROWS, XCD><<<B, 64>>>(traj, R);
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) k<CHUNK_ROWS, XCD><<<B, 64>>>(traj, R);
+    (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     printf("%-44s R=%d: %.3f ms => %.2f TB/s\n", what, R, ms, (double)B * R * 88 / ms / 1e9);
 }
 int main() {
@@ -37,6 +39,8 @@ int main() {
         run<256>(traj, B, 1306, "256-row pieces, blocks 16-B aligned");
         run<256>(traj, B, 1312, "256-row pieces, blocks line aligned");
         run<1312>(traj, B, 1312, "whole mission in one sweep, line aligned");
+        run<64, 1>(traj, B, 1306, "64-row chunks, XCD-contiguous missions");
+        run<64, 1>(traj, B, 1312, "64-row chunks, XCD-contiguous, line aligned");
     }
     return 0;
 }

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     int *pre = reinterpret_cast<int *>(cl + 24 * m);   // [m+1] exclusive prefix of seg_rows
 
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b = xcd_contiguous(blockIdx.x, gridDim.x);      // consecutive missions (consecutive rows in HBM) per XCD
     const int64_t row0 = row_offsets[b];
     const int N = (int)(row_offsets[b + 1] - row0);
 
@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
         if (first_here && c0 > 0) {
             // the first usable heading arrived after whole chunks of placeholders: patch their yaw column
             // (same wave, same addresses, program order => the later store wins)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // those rows' own stores have landed (once per mission at most)
             for (int i = lane; i < c0; i += SB) traj[(row0 + i) * UAVAC_TRAJ_COLS + 9] = first_yaw;
         }
         // carries (wave-uniform)
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             o[0] = px; o[1] = py; o[2] = pz; o[3] = vx; o[4] = vy; o[5] = vz;
             o[6] = ax; o[7] = ay; o[8] = az; o[9] = yaw; o[10] = (double)s;
         }
-        __syncthreads();                          // single wave: orders the LDS writes before the reads below
+        lds_wave_fence();                         // single wave: orders the LDS writes before the reads below
 
         // coalesced write-out of the staged chunk: 16-byte stores from an even element index
         const int nrows = min(SB, N - c0);
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             *reinterpret_cast<double2 *>(dst + head + 2 * p) = v;
         }
         if (((nel - head) & 1) && lane == 63) dst[nel - 1] = stage[nel - 1];
-        __syncthreads();
+        lds_wave_fence();                         // the staged chunk is in registers / on its way; its stores stay in flight
     }
 }
 

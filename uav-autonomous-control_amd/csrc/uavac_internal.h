@@ -35,6 +35,32 @@ static inline int uavac_fail(uavac_ctx *ctx, int code, const char *msg) {
     return code;
 }
 
+// blockIdx -> tile such that the blocks of one XCD own a contiguous range of tiles; a bijection on [0, n) for every
+// n.  Workgroups go to the chip's 8 XCDs round-robin (blockIdx % 8); when consecutive tiles are consecutive in memory,
+// this gives every XCD's L2 one contiguous span to stream to HBM instead of every eighth piece.  Store-only probes:
+// the sampler's write pattern 5.6 -> 6.7 TB/s, the rollout's log 5.4 -> 6.3 TB/s (tools/sampler_store_probe.hip,
+// tools/log_layout_probe.hip).
+#ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a release/acquire fence for GLOBAL memory:
+// the compiler puts `s_waitcnt vmcnt(0)` in front of it, so a wave that has stores (or a prefetch) in flight waits
+// for their completion -- a full HBM round trip -- at every barrier.  The kernels here hand data over through LDS
+// and never read back what they store to HBM, so they wait for LDS (lgkmcnt) alone and leave vector-memory
+// operations in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// Same for a workgroup that is a single wavefront: LDS operations of one wave execute in order, so only the
+// compiler needs to be told not to move memory accesses across this point.
+__device__ __forceinline__ void lds_wave_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ int xcd_contiguous(int block, int n) {
+    const int x = block & 7, q = n >> 3, r = n & 7;
+    return x * q + (x < r ? x : r) + (block >> 3);
+}
+#endif
+
 // Kernel-side view of uavac_vehicle with the per-call constants hoisted on the host.
 struct VehK {
     double g, dt, dt_outer, mass, inv_mass;
