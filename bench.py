@@ -212,7 +212,7 @@ def main():
                        "batch_per_gpu": B, "segments": m, "ticks": TICKS, "ticks_per_launch": CHUNK,
                        "velocity": VELOCITY, "dt": DT, "inner_per_outer": F, "rows": plan.total_rows,
                        "parallelism": f"missions sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "control_rollout_kernel<1, true, false, false>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "control_rollout_kernel<1, true, false, false, true>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": roll_bytes, "avg_launch_ms": roll_avg_s * 1e3,
                          "fp64_valu": {"lane_instr_per_tick": FP64_VALU_PER_TICK,

@@ -112,6 +112,11 @@ int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double 
  * aabb[6] = xmin xmax ymin ymax zmin zmax (device pointer; inclusive test of is_collision_cuboid :327-357):
  * hit [B][m] i32 (0/1).  This is the collision scan of _generate_collision_free_trajectory (:81-87), fused
  * into the sampling pass; the midpoint insertion that follows (:91-92) is host logic. */
+/* uavac_minsnap_sample_dev that also writes the yaw column on its own: yaw[row_offsets[B]]
+ * (yaw[i] == traj[i][9]); input of uavac_control_rollout_plan_dev. */
+int uavac_minsnap_sample_yaw_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
+                                 const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
+                                 double dt, double *traj, double *yaw);
 int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
                                   const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                                   double dt, double *traj, const double *aabb, int32_t *hit);
@@ -154,6 +159,17 @@ int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const doub
                               const int64_t *row_offsets, double *state, int32_t *istate, int B,
                               int K, double *state_log, double *cmd_log, const double *aabbs,
                               int n_obs);
+/* The same rollout fed by the plan instead of the sampled rows: the target row of every outer tick is
+ * evaluated inside the kernel from the coefficients of the UAV's current segment (bit-identical to
+ * the sampler's rows), the yaw comes from the dense yaw column uavac_minsnap_sample_yaw_dev writes.
+ * coeffs [B][8m][3], seg_rows [B][m], row_offsets [B+1], yaw [row_offsets[B]], dt as given to the
+ * sampler.  Same results as uavac_control_rollout_dev on the sampled trajectory, without its HBM
+ * read traffic (80 B per UAV and outer tick, fetched as 128-byte lines). */
+int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *coeffs,
+                                   const int32_t *seg_rows, const int64_t *row_offsets,
+                                   const double *yaw, int m, double dt, double *state,
+                                   int32_t *istate, int B, int K, double *state_log,
+                                   double *cmd_log, const double *aabbs, int n_obs);
 /* One tick (K = 1, no logs): the literal drop-in of tc.step() + simulation.step(). */
 int uavac_control_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
                            const int64_t *row_offsets, double *state, int32_t *istate, int B);

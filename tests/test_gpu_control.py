@@ -469,3 +469,28 @@ def test_logged_rollout_beyond_one_launch_is_split_without_a_trace(eng):
     nolog = eng.fleet(eng.plan(wps, 3.0, 0.01))
     nolog.rollout(K)                                                          # one launch, no log: same states
     assert torch.equal(nolog.state, big.state)
+
+
+def test_plan_fed_rollout_equals_row_fed_rollout(eng):
+    """Fleet(from_plan=True) evaluates every target row inside the kernel from the segment coefficients (+ the dense
+    yaw column); Fleet(from_plan=False) reads the sampled rows.  Same bits: states, logs, cursors -- in one launch,
+    across split launches (the cursor's segment / row-in-segment are rebuilt from the index) and tick by tick."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    for B, m, K in ((130, 3, 2600), (257, 12, 700), (64, 1, 900)):
+        wps = mo.synthetic_missions(B, m)
+        plan = eng.plan(wps, 3.0, 0.01)
+        assert torch.equal(plan.yaw, plan.traj[:, 9])
+        a, b = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False)
+        assert a.from_plan and not b.from_plan
+        la, ca = a.rollout(K, state_log=True, cmd_log=True)
+        lb, cb = b.rollout(K, state_log=True, cmd_log=True)
+        assert torch.equal(la, lb) and torch.equal(ca, cb)
+        assert torch.equal(a.state, b.state) and torch.equal(a.istate, b.istate)
+        c = eng.fleet(plan, from_plan=True)
+        for k in (1, 7, 16 * 10, 333, K - 1 - 7 - 160 - 333):           # odd split points, one past a yaw refill
+            c.rollout(k)
+        assert torch.equal(c.state, a.state) and torch.equal(c.istate, a.istate)
+    # far beyond the end of the trajectory the last row is held
+    a.rollout(3000); b.rollout(3000)
+    assert torch.equal(a.state, b.state) and torch.equal(a.istate, b.istate)

@@ -27,6 +27,7 @@
 //   sets the pace and the arithmetic hides under it.
 
 #include "control_law.h"
+#include "minsnap_eval.h"
 
 #include <cmath>
 
@@ -85,12 +86,20 @@ __device__ __forceinline__ VehK outer_constants() {
 
 // CW: compute waves per workgroup (UAVs per workgroup = 64 CW).  LDS slab layout: [2][NR][64 CW] doubles,
 // NR = 13 state rows (+ 12 command rows).
-template <int CW, bool LOG_STATE, bool LOG_CMD, bool AABB>
+// POLY: the target row of an outer tick is not read from the sampled trajectory but evaluated from the 24
+// coefficients of the UAV's current segment (the sampler's own function, bit for bit: minsnap_eval.h), with the
+// yaw -- the one column that is a scan over all earlier rows -- taken from the sampler's dense yaw array 16 rows at
+// a time.  Per UAV and outer tick that is 8 B of yaw plus 192 B of coefficients per ~110 rows instead of an 80-B
+// row whose 128-B lines the log stream has evicted from L2 by the next outer tick: HBM read traffic per launch
+// drops from 1.3 GB to 0.1 GB at B = 65 536.  Coefficients [24][64] and yaws [16][64] of a compute wave live in LDS.
+constexpr int kPolyTileDoubles = (24 + 16) * 64;
+
+template <int CW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY>
 __global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD) ? 64 : 0))
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
                        double *__restrict__ state_log, double *__restrict__ cmd_log,
-                       const double *__restrict__ aabbs, int n_obs, int col_base) {
+                       const double *__restrict__ aabbs, int n_obs, int col_base, const PlanRef P) {
     constexpr bool LOGGING = LOG_STATE || LOG_CMD;
     constexpr int NU = 64 * CW;                                        // UAVs per workgroup
     constexpr int NR = (LOG_STATE ? 13 : 0) + (LOG_CMD ? UAVAC_CMD_COLS : 0);
@@ -178,7 +187,33 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     settle(idx); settle(phase); settle(collided);
 
     RowRegs nxt;
-    if (nrows > 0) row_issue(nxt, rows + (size_t)min(max(idx, 0), nrows - 1) * UAVAC_TRAJ_COLS);
+    if (!POLY && nrows > 0) row_issue(nxt, rows + (size_t)min(max(idx, 0), nrows - 1) * UAVAC_TRAJ_COLS);
+
+    // POLY: segment / row-in-segment of the cursor, the segment's coefficients and the next 16 yaws, in LDS
+    double *cf = slab + (size_t)2 * NR * NU + (size_t)(tid >> 6) * kPolyTileDoubles + (tid & 63);      // cf[j * 64]
+    double *yw = cf + 24 * 64;                                                                          // yw[j * 64]
+    const int32_t *seg_rows = POLY ? P.seg_rows + (size_t)bb * P.m : nullptr;
+    const double *mission_coeffs = POLY ? P.coeffs + (size_t)bb * 24 * P.m : nullptr;
+    const double *yaws = POLY ? P.yaw + off : nullptr;
+    int seg = 0, rin = 0, srows = 0, ybase = 0;
+    auto load_coeffs = [&](int s_) {
+        const double *src = mission_coeffs + 24 * s_;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) cf[j * 64] = src[j];
+    };
+    auto load_yaws = [&](int base_) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) yw[j * 64] = yaws[min(base_ + j, nrows - 1)];
+    };
+    if (POLY && nrows > 0) {
+        idx = min(max(idx, 0), nrows - 1);
+        rin = idx;
+        srows = seg_rows[0];
+        while (seg + 1 < P.m && rin >= srows) { rin -= srows; ++seg; srows = seg_rows[seg]; }
+        load_coeffs(seg);
+        ybase = idx;
+        load_yaws(ybase);
+    }
 
     // 1/|q|^2 of the caller-supplied attitude; the free-body step leaves q unit, so 1 from then on
     // (a state this kernel wrote earlier is unit to rounding: take exactly 1 so that splitting a rollout over
@@ -189,11 +224,17 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     for (int k = 0; k < K; ++k) {
         if (phase == 0 && nrows > 0) {
             // ------------------------------------------------------------- outer loop (main.py:47-61)
-            row_wait(nxt);
-            const double tg_x = row_col(nxt, 0), tg_y = row_col(nxt, 1), tg_z = row_col(nxt, 2);
-            const double tg_vx = row_col(nxt, 3), tg_vy = row_col(nxt, 4), tg_vz = row_col(nxt, 5);
-            const double tg_ax = row_col(nxt, 6), tg_ay = row_col(nxt, 7), tg_az = row_col(nxt, 8);
-            const double tg_yaw = row_col(nxt, 9);
+            double tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az, tg_yaw;
+            if (POLY) {
+                minsnap_eval_row<64>(cf, (double)rin * P.dt, tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az);
+                tg_yaw = yw[(idx - ybase) * 64];
+            } else {
+                row_wait(nxt);
+                tg_x = row_col(nxt, 0); tg_y = row_col(nxt, 1); tg_z = row_col(nxt, 2);
+                tg_vx = row_col(nxt, 3); tg_vy = row_col(nxt, 4); tg_vz = row_col(nxt, 5);
+                tg_ax = row_col(nxt, 6); tg_ay = row_col(nxt, 7); tg_az = row_col(nxt, 8);
+                tg_yaw = row_col(nxt, 9);
+            }
 
             const VehK O = outer_constants();
             const Rot R = quat_to_rot(q0, q1, q2, q3);                 // shared by altitude and attitude
@@ -206,8 +247,16 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             rc = yaw_rate(O, tg_yaw, psi, cth, sphi, cphi, qc);
             // next row (main.py:61), consumed F ticks from now; issued last so that nothing in this block
             // still reads the registers it overwrites
-            idx = min(idx + 1, nrows - 1);
-            row_issue(nxt, rows + (size_t)idx * UAVAC_TRAJ_COLS);
+            if (POLY) {
+                if (idx + 1 < nrows) {                    // main.py:61: the cursor stops on the last row
+                    ++idx;
+                    if (++rin == srows) { ++seg; rin = 0; srows = seg_rows[seg]; load_coeffs(seg); }
+                    if (idx - ybase == 16) { ybase = idx; load_yaws(ybase); }
+                }
+            } else {
+                idx = min(idx + 1, nrows - 1);
+                row_issue(nxt, rows + (size_t)idx * UAVAC_TRAJ_COLS);
+            }
         }
 
         // ----------------------------------------------------------------- inner loop, every tick
@@ -247,7 +296,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         phase = (phase + 1 == V.F) ? 0 : phase + 1;
     }
 
-    if (nrows > 0) row_wait(nxt);          // nothing may stay in flight into these registers
+    if (!POLY && nrows > 0) row_wait(nxt);          // nothing may stay in flight into these registers
     if (!live) return;
 
     state[0 * sB + b] = px; state[1 * sB + b] = py; state[2 * sB + b] = pz;
@@ -284,14 +333,15 @@ __global__ void state_init_kernel(const VehK V, const double *__restrict__ posit
 
 constexpr int kColumnsPerLaunch = 256 * 4 * 64;          // one 64-UAV workgroup per SIMD of the chip
 
-template <int CW, bool LS, bool LC, bool AB>
-void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
-                    int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs) {
+template <int CW, bool LS, bool LC, bool AB, bool POLY>
+void launch_poly(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
+                 int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
+                 const PlanRef &P) {
     constexpr int NU = 64 * CW;
     constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0);
     constexpr int threads = NU + ((LS || LC) ? 64 : 0);
-    const size_t lds = sizeof(double) * 2 * NR * NU;
-    auto kern = control_rollout_kernel<CW, LS, LC, AB>;
+    const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * kPolyTileDoubles : 0));
+    auto kern = control_rollout_kernel<CW, LS, LC, AB, POLY>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // With logs, batches beyond one workgroup per SIMD go out as consecutive launches of kColumnsPerLaunch UAVs:
     // measured per 1 000 ticks, B = 131 072 in one launch 4.04 ms, as 2 x 65 536 3.3 ms (two workgroups per SIMD
@@ -300,15 +350,24 @@ void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int
     for (int base = 0; base < B; base += per_launch) {
         const int cols = (B - base < per_launch) ? B - base : per_launch;
         hipLaunchKernelGGL(kern, dim3((cols + NU - 1) / NU), dim3(threads), lds, ctx->stream, V, traj, row_offsets, state,
-                           istate, B, K, state_log, cmd_log, aabbs, n_obs, base);
+                           istate, B, K, state_log, cmd_log, aabbs, n_obs, base, P);
     }
+}
+
+template <int CW, bool LS, bool LC, bool AB>
+void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
+                    int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
+                    const PlanRef *plan) {
+    if (plan) launch_poly<CW, LS, LC, AB, true>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, *plan);
+    else launch_poly<CW, LS, LC, AB, false>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, PlanRef{});
 }
 
 template <int CW>
 void launch_cw(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
-               int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs) {
+               int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
+               const PlanRef *plan) {
     const bool ls = state_log != nullptr, lc = cmd_log != nullptr, ab = (aabbs != nullptr && n_obs > 0);
-#define UAVAC_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs
+#define UAVAC_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, plan
     if (ls) {
         if (lc) { if (ab) launch_variant<CW, true, true, true>(UAVAC_ARGS); else launch_variant<CW, true, true, false>(UAVAC_ARGS); }
         else    { if (ab) launch_variant<CW, true, false, true>(UAVAC_ARGS); else launch_variant<CW, true, false, false>(UAVAC_ARGS); }
@@ -331,7 +390,7 @@ int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positio
 
 int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                          int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,
-                         int n_obs) {
+                         int n_obs, const PlanRef *plan) {
     // One compute wave + one store wave per workgroup.  (Four compute waves sharing one store wave were
     // measured 15 % slower at B = 65 536: a single wave cannot issue a CU's 52 stores per tick fast enough.
     // Two compute waves with the store wave moving 16 B per lane -- 13 x 1 KB wave stores per tick instead of
@@ -340,7 +399,7 @@ int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, cons
     // LDS, so that the compute wave may run 4 ticks ahead of a stalled store wave, was slower as well: 1.35 vs
     // 1.26 ms -- the hand-over is not what limits the kernel.)  The log rows want B to be a multiple of 16 (128-B lines): B = 65 534 runs at half
     // the rate of B = 65 536 because every 512-B wave store then straddles two partially written lines.
-    launch_cw<1>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs);
+    launch_cw<1>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, plan);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

@@ -1,0 +1,22 @@
+// One trajectory sample from the 24 coefficients of its segment: position, velocity, acceleration on the three
+// axes at local time t (minimum_snap.py:100-119, polynom :257-286).  Shared by the sampler and by the rollout
+// variant that evaluates rows itself, so that both produce the SAME bits: every multiply-add is an explicit fma.
+//
+// Horner with running derivatives: p, p' and p''/2 cost three FMAs per power and axis, no i * c_i products.
+// c[(3 i + axis) * STRIDE] = coefficient of t^i (STRIDE 1: the mission's (8,3) block; 64: a [24][64] LDS tile).
+#pragma once
+
+template <int STRIDE>
+__device__ __forceinline__ void minsnap_eval_row(const double *c, double t, double &px, double &py, double &pz,
+                                                 double &vx, double &vy, double &vz, double &ax, double &ay, double &az) {
+    double d1x = 0, d1y = 0, d1z = 0, d2x = 0, d2y = 0, d2z = 0;
+    px = c[21 * STRIDE]; py = c[22 * STRIDE]; pz = c[23 * STRIDE];
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+        d2x = fma(d2x, t, d1x); d2y = fma(d2y, t, d1y); d2z = fma(d2z, t, d1z);
+        d1x = fma(d1x, t, px);  d1y = fma(d1y, t, py);  d1z = fma(d1z, t, pz);
+        px = fma(px, t, c[(3 * i) * STRIDE]); py = fma(py, t, c[(3 * i + 1) * STRIDE]); pz = fma(pz, t, c[(3 * i + 2) * STRIDE]);
+    }
+    vx = d1x; vy = d1y; vz = d1z;
+    ax = 2.0 * d2x; ay = 2.0 * d2y; az = 2.0 * d2z;
+}

@@ -13,6 +13,7 @@
 // row-major (N,11) output leaves as contiguous 16-byte stores (5.6 KB per chunk).
 
 #include "uavac_internal.h"
+#include "minsnap_eval.h"
 
 namespace {
 
@@ -53,7 +54,8 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                                                            const int32_t *__restrict__ seg_rows,
                                                            const int64_t *__restrict__ row_offsets, int B, int m,
                                                            double dt, double *__restrict__ traj,
-                                                           const double *__restrict__ aabb, int32_t *__restrict__ hit) {
+                                                           const double *__restrict__ aabb, int32_t *__restrict__ hit,
+                                                           double *__restrict__ yaw_dense) {
     extern __shared__ double lds[];
     double *stage = lds;                         // [SB*11]
     double *cl = stage + SB * UAVAC_TRAJ_COLS;   // [24*m] coefficients of this mission
@@ -91,17 +93,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             s = segment_of(pre, m, r, s);
             const double t = (double)(r - pre[s]) * dt;
             const double *c = cl + s * 24;
-            // Horner with running derivatives: p, p' and p''/2 cost 3 FMAs per power and axis, no i*c_i products
-            double d1x = 0, d1y = 0, d1z = 0, d2x = 0, d2y = 0, d2z = 0;
-            px = c[21]; py = c[22]; pz = c[23];
-#pragma unroll
-            for (int i = 6; i >= 0; --i) {
-                d2x = d2x * t + d1x; d2y = d2y * t + d1y; d2z = d2z * t + d1z;
-                d1x = d1x * t + px;  d1y = d1y * t + py;  d1z = d1z * t + pz;
-                px = px * t + c[3 * i]; py = py * t + c[3 * i + 1]; pz = pz * t + c[3 * i + 2];
-            }
-            vx = d1x; vy = d1y; vz = d1z;
-            ax = 2.0 * d2x; ay = 2.0 * d2y; az = 2.0 * d2z;
+            minsnap_eval_row<1>(c, t, px, py, pz, vx, vy, vz, ax, ay, az);
         }
         if (HITS) {
             // inclusive AABB test on the sampled position (minimum_snap.py:327-357); flags the row's spline
@@ -140,11 +132,14 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             // (same wave, same addresses, program order => the later store wins)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // those rows' own stores have landed (once per mission at most)
             for (int i = lane; i < c0; i += SB) traj[(row0 + i) * UAVAC_TRAJ_COLS + 9] = first_yaw;
+            if (yaw_dense)
+                for (int i = lane; i < c0; i += SB) yaw_dense[row0 + i] = first_yaw;
         }
         // carries (wave-uniform)
         carry_sum += lane_value(incl, 63);
         if (mask != 0ull) { carry_has = true; carry_ang = lane_value(ang, 63 - __clzll((long long)mask)); }
 
+        if (active && yaw_dense) yaw_dense[row0 + r] = yaw;      // the yaw column on its own, 512 B per chunk
         if (active) {
             double *o = stage + lane * UAVAC_TRAJ_COLS;
             o[0] = px; o[1] = py; o[2] = pz; o[3] = vx; o[4] = vy; o[5] = vz;
@@ -173,15 +168,15 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
 }  // namespace
 
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
-                        int B, int m, double dt, double *traj, const double *aabb, int32_t *hit) {
+                        int B, int m, double dt, double *traj, const double *aabb, int32_t *hit, double *yaw_dense) {
     size_t lds = sizeof(double) * ((size_t)SB * UAVAC_TRAJ_COLS + (size_t)24 * m) + sizeof(int) * (size_t)(m + 2);
     if (aabb && hit) {
         UAVAC_HIP(ctx, hipMemsetAsync(hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
         hipLaunchKernelGGL(minsnap_sample_kernel<true>, dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows,
-                           row_offsets, B, m, dt, traj, aabb, hit);
+                           row_offsets, B, m, dt, traj, aabb, hit, yaw_dense);
     } else {
         hipLaunchKernelGGL(minsnap_sample_kernel<false>, dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows,
-                           row_offsets, B, m, dt, traj, aabb, hit);
+                           row_offsets, B, m, dt, traj, aabb, hit, yaw_dense);
     }
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;

@@ -178,6 +178,15 @@ int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double 
     return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj);
 }
 
+int uavac_minsnap_sample_yaw_dev(uavac_ctx *ctx, const double *coeffs, const double *times, const int32_t *seg_rows,
+                                 const int64_t *row_offsets, int B, int m, double dt, double *traj, double *yaw) {
+    (void)times;
+    if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
+    if (!seg_rows || !row_offsets || !traj || !yaw) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, nullptr, nullptr, yaw);
+}
+
 int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const double *times, const int32_t *seg_rows,
                                   const int64_t *row_offsets, int B, int m, double dt, double *traj,
                                   const double *aabb, int32_t *hit) {
@@ -296,6 +305,23 @@ int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const doub
     if (K == 0) return UAVAC_OK;
     return uavac_launch_rollout(ctx, uavac_make_vehk(*V), traj, row_offsets, state, istate, B, K, state_log, cmd_log,
                                 aabbs, n_obs);
+}
+
+int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *coeffs, const int32_t *seg_rows,
+                                   const int64_t *row_offsets, const double *yaw, int m, double dt, double *state,
+                                   int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,
+                                   int n_obs) {
+    if (!ctx) return UAVAC_EINVAL;
+    if (int rc = uavac_check_vehicle(ctx, V)) return rc;
+    if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
+    if (K < 0 || !seg_rows || !row_offsets || !yaw || !state || !istate || n_obs < 0)
+        return uavac_fail(ctx, UAVAC_EINVAL, "bad size or null pointer");
+    if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
+    if (K == 0) return UAVAC_OK;
+    PlanRef plan;
+    plan.coeffs = coeffs; plan.seg_rows = seg_rows; plan.yaw = yaw; plan.dt = dt; plan.m = m;
+    return uavac_launch_rollout(ctx, uavac_make_vehk(*V), nullptr, row_offsets, state, istate, B, K, state_log, cmd_log,
+                                aabbs, n_obs, &plan);
 }
 
 int uavac_control_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,

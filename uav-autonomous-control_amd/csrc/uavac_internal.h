@@ -86,9 +86,18 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
 int uavac_launch_solve(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                        int32_t *status);
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
-                        int B, int m, double dt, double *traj, const double *aabb = nullptr, int32_t *hit = nullptr);
+                        int B, int m, double dt, double *traj, const double *aabb = nullptr, int32_t *hit = nullptr,
+                        double *yaw_dense = nullptr);
 int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positions, int B, int hover, double *state,
                             int32_t *istate);
+// What the rollout needs to evaluate target rows itself instead of reading them (control_rollout.hip, POLY)
+struct PlanRef {
+    const double *coeffs = nullptr;      // [B][8m][3]
+    const int32_t *seg_rows = nullptr;   // [B][m]
+    const double *yaw = nullptr;         // [row_offsets[B]] dense yaw column of the sampler
+    double dt = 0.0;
+    int m = 0;
+};
 int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                          int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,
-                         int n_obs);
+                         int n_obs, const PlanRef *plan = nullptr);

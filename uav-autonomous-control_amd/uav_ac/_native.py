@@ -62,12 +62,15 @@ _SIGNATURES = {
     "uavac_minsnap_solve_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "uavac_minsnap_solve_banded_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "uavac_minsnap_sample_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P]),
+    "uavac_minsnap_sample_yaw_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_minsnap_sample_hits_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
     "uavac_minsnap_row_counts": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
     "uavac_minsnap_solve": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_minsnap_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_state_init_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
     "uavac_control_rollout_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
+    "uavac_control_rollout_plan_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_double, _P, _P,
+                                                  C.c_int, C.c_int, _P, _P, _P, C.c_int]),
     "uavac_control_step_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
     "uavac_state_init": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
     "uavac_control_rollout": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),

@@ -43,6 +43,7 @@ class Plan:
     status: "object"         # (B,) i32: 0 ok, 1 singular
     traj: "object"           # (N, 11) f64, missions back to back
     total_rows: int
+    yaw: "object" = None     # (N,) f64: the yaw column on its own (== traj[:, 9]); feeds the plan-fed rollout
 
     def mission(self, b: int) -> np.ndarray:
         """Rows of mission b as a fresh host array (N_b, 11) -- the reference's `full_trajectory`."""
@@ -140,7 +141,8 @@ class Engine:
         self.ctx.call("uavac_minsnap_solve_dev", _ptr(wp), _ptr(times), B, m, _ptr(coeffs), _ptr(status))
         total = int(row_offsets[-1].item())                 # the one host sync: sizes the trajectory buffer
         traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
-        plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total)
+        yaw = torch.empty((total,), dtype=torch.float64, **kw)
+        plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw)
         self.sample(plan)
         return plan
 
@@ -283,8 +285,12 @@ class Engine:
     def sample(self, plan: Plan):
         """Re-run the sampler + yaw scan into plan.traj (no allocation, no sync)."""
         self._bind_stream()
-        self.ctx.call("uavac_minsnap_sample_dev", _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows),
-                      _ptr(plan.row_offsets), plan.B, plan.m, plan.dt, _ptr(plan.traj))
+        if plan.yaw is None:
+            self.ctx.call("uavac_minsnap_sample_dev", _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows),
+                          _ptr(plan.row_offsets), plan.B, plan.m, plan.dt, _ptr(plan.traj))
+        else:
+            self.ctx.call("uavac_minsnap_sample_yaw_dev", _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows),
+                          _ptr(plan.row_offsets), plan.B, plan.m, plan.dt, _ptr(plan.traj), _ptr(plan.yaw))
 
     def check(self, plan: Plan):
         """Raise like the C ABI's host twins would: singular knot systems (repeated waypoints)."""
@@ -371,16 +377,22 @@ class Engine:
 
     # -- control ----------------------------------------------------------------
     def fleet(self, plan: Plan, vehicle: Optional[nat.Vehicle] = None, hover: bool = True,
-              positions=None) -> "Fleet":
-        return Fleet(self, plan, vehicle, hover, positions)
+              positions=None, from_plan=None) -> "Fleet":
+        return Fleet(self, plan, vehicle, hover, positions, from_plan)
 
 
 class Fleet:
     """B UAVs tracking the B missions of a Plan: batched TrajectoryController + free-flight simulation."""
 
-    def __init__(self, engine: Engine, plan: Plan, vehicle=None, hover=True, positions=None):
+    def __init__(self, engine: Engine, plan: Plan, vehicle=None, hover=True, positions=None, from_plan=None):
         torch = engine._torch
         self.engine, self.plan = engine, plan
+        # from_plan: feed the rollout with the plan's coefficients + dense yaw column (rows evaluated in the kernel)
+        # instead of the sampled rows.  Default: whenever the plan carries them (a RaggedPlan does not).
+        can = getattr(plan, "yaw", None) is not None and hasattr(plan, "coeffs")
+        self.from_plan = can if from_plan is None else bool(from_plan)
+        if self.from_plan and not can:
+            raise ValueError("this plan has no coefficients / yaw column to fly from")
         self.vehicle = vehicle if vehicle is not None else nat.Vehicle.default()
         self.B = plan.B
         self.state = torch.empty((nat.STATE_ROWS, self.B), dtype=torch.float64, device=engine.device)
@@ -419,9 +431,15 @@ class Fleet:
             ab = e._dev(aabbs, torch.float64).reshape(-1, 6)
             n_obs = int(ab.shape[0])
         e._bind_stream()
-        e.ctx.call("uavac_control_rollout_dev", C.byref(self.vehicle), _ptr(self.plan.traj),
-                   _ptr(self.plan.row_offsets), _ptr(self.state), _ptr(self.istate), self.B, int(K),
-                   _ptr(state_log), _ptr(cmd_log), _ptr(ab), n_obs)
+        p = self.plan
+        if self.from_plan:
+            # target rows are evaluated inside the kernel from the plan's coefficients (+ its dense yaw column)
+            e.ctx.call("uavac_control_rollout_plan_dev", C.byref(self.vehicle), _ptr(p.coeffs), _ptr(p.seg_rows),
+                       _ptr(p.row_offsets), _ptr(p.yaw), p.m, float(p.dt), _ptr(self.state), _ptr(self.istate), self.B,
+                       int(K), _ptr(state_log), _ptr(cmd_log), _ptr(ab), n_obs)
+        else:
+            e.ctx.call("uavac_control_rollout_dev", C.byref(self.vehicle), _ptr(p.traj), _ptr(p.row_offsets),
+                       _ptr(self.state), _ptr(self.istate), self.B, int(K), _ptr(state_log), _ptr(cmd_log), _ptr(ab), n_obs)
         return state_log, cmd_log
 
     def step(self):
