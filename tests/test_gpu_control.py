@@ -494,3 +494,16 @@ def test_plan_fed_rollout_equals_row_fed_rollout(eng):
     # far beyond the end of the trajectory the last row is held
     a.rollout(3000); b.rollout(3000)
     assert torch.equal(a.state, b.state) and torch.equal(a.istate, b.istate)
+
+
+def test_fleet_picks_the_rollout_feed_by_batch_size(eng):
+    from oracle import minsnap_oracle as mo
+    from uav_ac.fleet import Fleet
+    small = eng.fleet(eng.plan(mo.synthetic_missions(64, 2), 3.0, 0.01))
+    assert small.from_plan is False
+    big = eng.fleet(eng.plan(mo.synthetic_missions(Fleet.PLAN_FED_MIN_BATCH, 1), 3.0, 0.01))
+    assert big.from_plan is True
+    ragged = eng.plan_collision_free([mo.synthetic_missions(1, 3)[0]], None, 3.0, 0.01)
+    assert eng.fleet(ragged).from_plan is False
+    with pytest.raises(ValueError):
+        eng.fleet(ragged, from_plan=True)

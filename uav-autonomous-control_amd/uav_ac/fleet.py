@@ -383,14 +383,19 @@ class Engine:
 
 class Fleet:
     """B UAVs tracking the B missions of a Plan: batched TrajectoryController + free-flight simulation."""
+    PLAN_FED_MIN_BATCH = 40960
 
     def __init__(self, engine: Engine, plan: Plan, vehicle=None, hover=True, positions=None, from_plan=None):
         torch = engine._torch
         self.engine, self.plan = engine, plan
         # from_plan: feed the rollout with the plan's coefficients + dense yaw column (rows evaluated in the kernel)
-        # instead of the sampled rows.  Default: whenever the plan carries them (a RaggedPlan does not).
+        # instead of the sampled rows.  Same bits either way.  Default: when the plan carries them (a RaggedPlan does
+        # not) and the batch is large enough for HBM traffic to be what limits the kernel -- measured per 1 000 logged
+        # ticks on an MI355X, plan-fed / row-fed: B = 32 768 1.05 / 0.95 ms, 49 152 1.08 / 1.11, 65 536 1.28 / 1.44,
+        # 131 072 2.58 / 3.01 (tools/plan_vs_rows.py); below ~40 000 UAVs the chip is not full and the extra
+        # arithmetic of evaluating rows costs more than the reads it saves.
         can = getattr(plan, "yaw", None) is not None and hasattr(plan, "coeffs")
-        self.from_plan = can if from_plan is None else bool(from_plan)
+        self.from_plan = (can and plan.B >= self.PLAN_FED_MIN_BATCH) if from_plan is None else bool(from_plan)
         if self.from_plan and not can:
             raise ValueError("this plan has no coefficients / yaw column to fly from")
         self.vehicle = vehicle if vehicle is not None else nat.Vehicle.default()
