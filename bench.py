@@ -89,8 +89,8 @@ def cpu_baseline(eng=None, wps=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="UAVs per GPU (default: config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
