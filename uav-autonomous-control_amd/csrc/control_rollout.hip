@@ -250,7 +250,10 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             if (POLY) {
                 if (idx + 1 < nrows) {                    // main.py:61: the cursor stops on the last row
                     ++idx;
-                    if (++rin == srows) { ++seg; rin = 0; srows = seg_rows[seg]; load_coeffs(seg); }
+                    if (++rin >= srows) {                 // next segment (skipping empty ones, like the sampler's segment_of)
+                        while (rin >= srows && seg + 1 < P.m) { rin -= srows; ++seg; srows = seg_rows[seg]; }
+                        load_coeffs(seg);
+                    }
                     if (idx - ybase == 16) { ybase = idx; load_yaws(ybase); }
                 }
             } else {
