@@ -507,3 +507,31 @@ def test_fleet_picks_the_rollout_feed_by_batch_size(eng):
     assert eng.fleet(ragged).from_plan is False
     with pytest.raises(ValueError):
         eng.fleet(ragged, from_plan=True)
+
+
+@pytest.mark.parametrize("m,velocity,dt,F", [(64, 6.0, 0.05, 3), (20, 3.0, 0.01, 10), (5, 30.0, 0.05, 1), (2, 0.7, 0.02, 7)])
+def test_plan_fed_rollout_corner_shapes(eng, nat, m, velocity, dt, F):
+    """Plan-fed == row-fed (bit for bit) on awkward plans: the maximum segment count, segments of one or two rows
+    (so that a cursor crosses several segments between yaw refills), another inner/outer ratio, with the per-tick
+    obstacle test and the command log."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    B, K = 192, 900
+    wps = mo.synthetic_missions(B, m, 0.4, 1.2)
+    plan = eng.plan(wps, velocity, dt)
+    eng.check(plan)
+    V = nat.Vehicle.default()
+    V.inner_per_outer = F
+    V.dt_outer = V.dt * F
+    aabbs = np.array([[1.0, 3.0, 1.0, 4.0, -4.0, -2.0], [10.0, 14.0, 5.0, 9.0, -3.5, -2.5]])
+    a, b = eng.fleet(plan, vehicle=V, from_plan=True), eng.fleet(plan, vehicle=V, from_plan=False)
+    la, ca = a.rollout(K, state_log=True, cmd_log=True, aabbs=aabbs)
+    lb, cb = b.rollout(K, state_log=True, cmd_log=True, aabbs=aabbs)
+    assert torch.equal(la, lb) and torch.equal(ca, cb)
+    assert torch.equal(a.state, b.state) and torch.equal(a.istate, b.istate)
+    rows = (plan.row_offsets[1:] - plan.row_offsets[:-1]).cpu().numpy()
+    assert rows.min() >= m and (a.trajectory_index.cpu().numpy() == np.minimum(K // F + (1 if K % F else 0), rows - 1)).all()
+    only_cmd_a, only_cmd_b = eng.fleet(plan, vehicle=V, from_plan=True), eng.fleet(plan, vehicle=V, from_plan=False)
+    _, c1 = only_cmd_a.rollout(300, cmd_log=True)
+    _, c2 = only_cmd_b.rollout(300, cmd_log=True)
+    assert torch.equal(c1, c2)
