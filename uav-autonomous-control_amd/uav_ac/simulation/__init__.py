@@ -1,0 +1,1 @@
+"""uav_ac.simulation -- drop-in module path of the reference package; the code computes on the GPU through libuavac.so."""
