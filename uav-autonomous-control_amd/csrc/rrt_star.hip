@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int W = 64;
-enum { RRT_OK = 0, RRT_NO_PATH = 1, RRT_COST_INCREASED = 2, RRT_KEY_ERROR = 3 };
+enum { RRT_OK = 0, RRT_NO_PATH = 1, RRT_COST_INCREASED = 2, RRT_KEY_ERROR = 3, RRT_OVERFLOW = 4 /* internal: rerun with full capacity */ };
 
 __device__ __forceinline__ double norm3(double x, double y, double z) { return sqrt(fma(z, z, fma(y, y, x * x))); }
 __device__ __forceinline__ double round2(double x) { return rint(x * 100.0) / 100.0; }
@@ -140,8 +140,13 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
                 const double *__restrict__ samples, const double *__restrict__ cuboids, int n_obs,
                 double *__restrict__ g_nodes, int32_t *__restrict__ g_canon, int32_t *__restrict__ g_parent,
                 int32_t *__restrict__ g_best_parent, double *__restrict__ g_best_path, int32_t *__restrict__ counts,
-                double *__restrict__ best_cost_out, double *__restrict__ scratch) {
+                double *__restrict__ best_cost_out, double *__restrict__ scratch, int node_cap, int pass) {
+    // Two passes share this kernel.  Pass 0 gives every problem LDS for `node_cap` nodes only (a typical tree uses a
+    // fraction of max_iter + 1), so several times more problems are resident per CU; a problem whose tree outgrows
+    // that stops with RRT_OVERFLOW.  Pass 1 (full capacity) reruns exactly those from the start; every other
+    // workgroup leaves at once.  Results do not depend on the split: a run is deterministic.
     constexpr bool use_lds = USE_LDS;
+    if (pass == 1 && counts[6 * blockIdx.x + 2] != RRT_OVERFLOW) return;
     extern __shared__ double lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int cap = max_iter + 1;
@@ -152,12 +157,13 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
     int32_t *best_parent = g_best_parent + b * capz;
     t.par = g_parent + b * capz;
     if (use_lds) {
+        const size_t ncz = (size_t)node_cap;
         t.nodes = lds;
-        t.elen = lds + 3 * capz;
-        t.cc = lds + 4 * capz;
-        t.canon = reinterpret_cast<int *>(lds + 5 * capz);
-        t.up = t.canon + capz;
-        t.nbr = t.up + capz;
+        t.elen = lds + 3 * ncz;
+        t.cc = lds + 4 * ncz;
+        t.canon = reinterpret_cast<int *>(lds + 5 * ncz);
+        t.up = t.canon + ncz;
+        t.nbr = t.up + ncz;
     } else {
         double *ws = scratch + (size_t)b * 3 * capz;       // elen, cc [cap] f64, up, nbr [cap] i32
         t.nodes = g_nodes + b * 3 * capz;
@@ -175,7 +181,8 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
     const double radius = 1.5 * step;
     const double break_at = (double)max_iter / 10.0;
 
-    for (int e = lane; e < cap; e += W) { parent[e] = -1; best_parent[e] = -1; t.up[e] = -1; t.canon[e] = -1; }
+    for (int e = lane; e < cap; e += W) { parent[e] = -1; best_parent[e] = -1; }
+    for (int e = lane; e < node_cap; e += W) { t.up[e] = -1; t.canon[e] = -1; }
     __syncthreads();
     if (lane == 0) {
         t.nodes[0] = start[0]; t.nodes[1] = start[1]; t.nodes[2] = start[2];
@@ -286,6 +293,7 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
                 const double cand = cost_to_come_cached(t, best_key, kerr) + edge;
                 if (current <= cand) link = false;
             }
+            if (link && n >= node_cap) { status = RRT_OVERFLOW; break; }      // pass 0 only: node_cap == cap otherwise
             if (link) {
                 const bool fresh = key < 0;
                 if (fresh) key = n;
@@ -374,6 +382,10 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
         }
     }
 
+    if (status == RRT_OVERFLOW) {               // nothing of this attempt is kept
+        if (lane == 0) counts[6 * b + 2] = RRT_OVERFLOW;
+        return;
+    }
     if (status == RRT_OK && !have_best) status = RRT_NO_PATH;
     __syncthreads();
     if (use_lds) {
@@ -381,7 +393,7 @@ rrt_star_kernel(const double *__restrict__ starts, const double *__restrict__ go
         for (int i = lane; i < 3 * n; i += W) gn[i] = t.nodes[i];
         for (int i = 3 * n + lane; i < 3 * cap; i += W) gn[i] = 0.0;
         int32_t *gc = g_canon + b * capz;
-        for (int e = lane; e < cap; e += W) gc[e] = t.canon[e];
+        for (int e = lane; e < cap; e += W) gc[e] = e < node_cap ? t.canon[e] : -1;
     } else {
         for (int i = 3 * n + lane; i < 3 * cap; i += W) t.nodes[i] = 0.0;
     }
@@ -623,9 +635,13 @@ int uavac_rrt_star_dev(uavac_ctx *ctx, const double *start, const double *goal, 
     if (!std::isfinite(step) || !(step > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "max_distance must be finite and > 0");
     if (n_obs < 0 || (n_obs > 0 && !cuboids)) return uavac_fail(ctx, UAVAC_EINVAL, "bad obstacle list");
     const int cap = max_iter + 1;
-    const size_t lds = kLdsBytesPerNode * (size_t)cap + 16;
-    const int use_lds = lds <= kLdsLimit;
-    if (!use_lds) {
+    // first-pass capacity: 384 nodes = 20 KB of LDS = 8 problems per CU (lab obstacle set, 1 000 iterations allowed:
+    // mean tree 210 nodes; measured at B = 16 384: one pass 49.6 ms, 256 / 384 / 512 nodes first 39.6 / 35.9 / 38.1 ms)
+    constexpr int kFirstPassNodes = 384;
+    const int small = kFirstPassNodes < cap ? kFirstPassNodes : cap;
+    const size_t lds_full = kLdsBytesPerNode * (size_t)cap + 16, lds_small = kLdsBytesPerNode * (size_t)small + 16;
+    const bool full_in_lds = lds_full <= kLdsLimit;
+    if (!full_in_lds) {
         const size_t need = scratch_doubles_per_problem(cap) * (size_t)B;
         if (need > ctx->ws_cap) {
             if (ctx->d_ws) UAVAC_HIP(ctx, hipFree(ctx->d_ws));
@@ -634,16 +650,26 @@ int uavac_rrt_star_dev(uavac_ctx *ctx, const double *start, const double *goal, 
             UAVAC_HIP(ctx, hipMalloc(&ctx->d_ws, need * sizeof(double)));
             ctx->ws_cap = need;
         }
-    } else if (lds > 64 * 1024) {
-        UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)rrt_star_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
     }
-    if (use_lds)
-        hipLaunchKernelGGL(rrt_star_kernel<true>, dim3(B), dim3(W), lds, ctx->stream, start, goal, B, step, max_iter, samples,
-                           cuboids, n_obs, nodes, canon, parent, best_parent, best_path, counts, best_cost, ctx->d_ws);
-    else
-        hipLaunchKernelGGL(rrt_star_kernel<false>, dim3(B), dim3(W), 0, ctx->stream, start, goal, B, step, max_iter, samples,
-                           cuboids, n_obs, nodes, canon, parent, best_parent, best_path, counts, best_cost, ctx->d_ws);
+    const size_t lds_max = full_in_lds ? lds_full : (lds_small <= kLdsLimit ? lds_small : 0);
+    if (lds_max > 64 * 1024)
+        UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)rrt_star_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_max));
+#define UAVAC_RRT_ARGS start, goal, B, step, max_iter, samples, cuboids, n_obs, nodes, canon, parent, best_parent, best_path, counts, \
+                       best_cost, ctx->d_ws
+    if (small < cap && lds_small <= kLdsLimit) {
+        // pass 0: small trees at high occupancy; pass 1: the overflowed problems with everything they may need
+        hipLaunchKernelGGL(rrt_star_kernel<true>, dim3(B), dim3(W), lds_small, ctx->stream, UAVAC_RRT_ARGS, small, 0);
+        if (full_in_lds)
+            hipLaunchKernelGGL(rrt_star_kernel<true>, dim3(B), dim3(W), lds_full, ctx->stream, UAVAC_RRT_ARGS, cap, 1);
+        else
+            hipLaunchKernelGGL(rrt_star_kernel<false>, dim3(B), dim3(W), 0, ctx->stream, UAVAC_RRT_ARGS, cap, 1);
+    } else if (full_in_lds) {
+        hipLaunchKernelGGL(rrt_star_kernel<true>, dim3(B), dim3(W), lds_full, ctx->stream, UAVAC_RRT_ARGS, cap, 0);
+    } else {
+        hipLaunchKernelGGL(rrt_star_kernel<false>, dim3(B), dim3(W), 0, ctx->stream, UAVAC_RRT_ARGS, cap, 0);
+    }
+#undef UAVAC_RRT_ARGS
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }
