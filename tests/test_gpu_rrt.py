@@ -220,6 +220,35 @@ def test_batched_simplify_matches_reference_and_facade():
     assert shorter > B // 2
 
 
+def test_edge_cases_match_oracle():
+    """Degenerate problems, each against the oracle: start == goal, goal walled in (no path), a single iteration, a step
+    longer than the space, a zero-volume cuboid, a start inside an obstacle, trees that overflow the first-pass
+    capacity by one node and by many."""
+    from oracle import c_oracle as co
+    from uav_ac.planning.rrt import draw_random_nodes_batch, rrt_star_batch
+    lw, up = np.array([0.0, 0.0, 0.0]), np.array([6.0, 6.0, 3.0])
+    box_in = np.array([[2.0, 4.0, 2.0, 4.0, -1.0, 4.0]])
+    cases = [
+        ("start == goal", [1.0, 1.0, 1.0], [1.0, 1.0, 1.0], 1.0, 60, None),
+        ("goal walled in", [0.5, 0.5, 0.5], [3.0, 3.0, 1.5], 0.8, 300, box_in),
+        ("one iteration", [0.5, 0.5, 0.5], [0.9, 0.5, 0.5], 1.0, 1, None),
+        ("step longer than the space", [0.5, 0.5, 0.5], [5.5, 5.5, 2.5], 50.0, 40, None),
+        ("zero-volume cuboid", [0.5, 0.5, 0.5], [5.5, 5.5, 2.5], 1.0, 200, np.array([[3.0, 3.0, 0.0, 6.0, 0.0, 3.0]])),
+        ("start inside an obstacle", [3.0, 3.0, 1.5], [5.5, 5.5, 2.5], 0.8, 200, box_in),
+        ("dense tree, small steps", [0.5, 0.5, 0.5], [5.5, 5.5, 2.5], 0.15, 2500, None),
+    ]
+    for name, start, goal, step, max_iter, obstacles in cases:
+        start, goal = np.array(start), np.array(goal)
+        samples = draw_random_nodes_batch([3, 4, 5], lw, up, np.stack([goal] * 3), max_iter)
+        res = rrt_star_batch(np.stack([start] * 3), np.stack([goal] * 3), step, samples, obstacles)
+        for b in range(3):
+            assert_same_as_oracle(res, b, co.rrt_star(start, goal, step, samples[b], obstacles))
+        if name == "goal walled in":
+            assert (res.status == 1).all()
+        if name == "dense tree, small steps":
+            assert res.n_nodes.max() > 384                    # crossed the first-pass capacity
+
+
 def test_large_tree_takes_the_scratch_path():
     """max_iterations too large for LDS (52 B per node > 160 KB): the same kernel on HBM scratch, same results."""
     from oracle import c_oracle as co
