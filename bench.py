@@ -225,6 +225,9 @@ def main():
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes": plan.algorithmic_bytes}},
+            "rollout_only": {"value": B * CHUNK / roll_avg_s, "unit": "UAV control-steps/s per GPU",
+                             "note": "SURVEY 8(d)(i): B x K / time of the rollout launches alone (`value` above also "
+                                     "carries the planning time of every step)"},
             "checks": {"frac_uavs_within_0.5m_of_target_row": frac_kept, "tracking_lanes_finite": finite_kept,
                        "all_trajectory_cursors_exact": cursor_ok},
         }
