@@ -5,11 +5,11 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/alu_store_overlap_probe.hip -o tools/alu_store_overlap_probe.bin 2>/dev/null
 #include <hip/hip_runtime.h>
 #include <cstdio>
-template <int MODE>      // 1 ALU, 2 store, 3 both, 7 both + barrier per tick, 15 = 7 + the values go through LDS slabs
+template <int MODE>      // 1 ALU, 2 store, 3 both, 7 both + barrier per tick, 15 = 7 + the values go through LDS slabs; +16: XCD-contiguous columns
 __global__ void __launch_bounds__(128) k(double *log, double *sink, int B, int K, int NF) {
     __shared__ double slab[2 * 13 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t g = blockIdx.x, sB = (size_t)B;
+    const size_t g = (MODE & 16) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x, sB = (size_t)B;
     if (wave == 0) {
         double a = 1.0 + lane, b = 2.0, c = 3.0, d = 4.0;
         for (int t = 0; t < K; ++t) {
@@ -55,9 +55,10 @@ int main() {
     if (hipMalloc(&log, (size_t)K * 13 * B * 8) != hipSuccess || hipMalloc(&sink, B * 8) != hipSuccess) return 1;
     for (int NF = 80; NF <= 240; NF += 40) {
         const float a = run<1>(log, sink, B, K, NF), s = run<2>(log, sink, B, K, NF), b = run<3>(log, sink, B, K, NF),
-                    bb = run<7>(log, sink, B, K, NF), bl = run<15>(log, sink, B, K, NF);
+                    bb = run<7>(log, sink, B, K, NF), bl = run<15>(log, sink, B, K, NF), sx = run<18>(log, sink, B, K, NF),
+                    blx = run<31>(log, sink, B, K, NF);
         printf("NF=%3d FMAs/tick: ALU only %.3f ms, stores only %.3f ms, both %.3f ms, both + barrier per tick %.3f ms, "
-               "+ LDS hand-over %.3f ms\n", NF, a, s, b, bb, bl);
+               "+ LDS hand-over %.3f ms | XCD-contiguous columns: stores only %.3f ms, full hand-over %.3f ms\n", NF, a, s, b, bb, bl, sx, blx);
     }
     return 0;
 }
