@@ -406,3 +406,19 @@ def test_randomised_shapes_velocities_and_steps(eng):
             assert got.shape == ref.shape, (B, m, vel, dt)
             assert np.array_equal(got[:, 10], ref[:, 10])
             assert col_err(got, ref) < 1e-7, (B, m, lo, hi, vel, dt)
+
+
+def test_dense_yaw_column_equals_the_rows_yaw(eng):
+    """Plan.yaw (written in groups of four chunks, with the back-fill of leading rows patched in LDS or in HBM
+    depending on whether the group had left) is column 9 of the rows, bit for bit -- including missions whose first
+    usable heading comes after several chunks and missions shorter than one group."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    rng = np.random.default_rng(8)
+    for B, m, vel, dt in ((200, 12, 3.0, 0.01), (64, 1, 3.0, 0.01), (77, 3, 0.4, 0.002), (50, 20, 6.0, 0.05)):
+        wps = mo.synthetic_missions(B, m)
+        wps[::3, 1:3, 0:2] = wps[::3, 0:1, 0:2]             # first legs vertical: no heading for hundreds of rows
+        plan = eng.plan(wps + rng.normal(0, 1e-9, wps.shape) * 0, vel, dt)
+        assert torch.equal(plan.yaw, plan.traj[:, 9])
+        eng.sample(plan)
+        assert torch.equal(plan.yaw, plan.traj[:, 9])
