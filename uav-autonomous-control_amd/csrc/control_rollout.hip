@@ -116,6 +116,13 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         const int lane = threadIdx.x - NU;
         __builtin_amdgcn_s_setprio(3);            // few instructions, all on the critical store stream: issue first
         const bool full = col0 + NU <= B;          // every column of this workgroup exists: no per-store mask
+        // With a state log the per-tick obstacle test runs HERE, on the positions this wave is about to store, after
+        // its stores have been issued: the compute wave's tick stays as short as without obstacles (the two stages
+        // couple through one barrier per tick; lengthening the compute stage to the length of the store stage cost
+        // 40 % at config 5), and the comparisons fill time in which this wave would wait for the store path anyway.
+        constexpr bool AABB_HERE = AABB && LOG_STATE && CW == 1;
+        const bool mine = col0 + lane < B;
+        int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
         for (int k = 0; k < K; ++k) {
             lds_barrier();                                             // slab k&1 is complete (stores of earlier ticks stay in flight)
             const double *src = slab + (size_t)(k & 1) * NR * NU + lane;
@@ -133,6 +140,15 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 #pragma unroll
                     for (int q = 0; q < CW; ++q)
                         if (full || col0 + q * 64 + lane < B) dst[r * sB + q * 64] = v[r][q];      // 512-B coalesced wave store
+                if (AABB_HERE) {
+                    const double x = v[0][0], y = v[1][0], z = v[2][0];
+                    for (int o = 0; o < n_obs; ++o) {
+                        const double *c = aabbs + 6 * o;          // uniform address: scalar loads
+                        const bool hit = (x >= c[0]) && (x <= c[1]) && (y >= c[2]) && (y <= c[3]) && (z >= c[4]) &&
+                                         (z <= c[5]);            // inclusive, minimum_snap.py:352-357
+                        coll |= hit ? 1 : 0;
+                    }
+                }
             }
             if (LOG_CMD) {
                 double v[UAVAC_CMD_COLS][CW];
@@ -148,6 +164,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                         if (full || col0 + q * 64 + lane < B) dst[r * sB + q * 64] = v[r][q];
             }
         }
+        if (AABB_HERE && mine) istate[2 * sB + col0 + lane] = coll;
         return;
     }
 
@@ -279,7 +296,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         free_body_step(V, om, px, py, pz, q0, q1, q2, q3, vx, vy, vz, wp, wq, wr, inv_n2);
         inv_n2 = 1.0;
 
-        if (AABB) {
+        if (AABB && !(LOG_STATE && CW == 1)) {             // with a state log the store wave tests the logged positions
             for (int o = 0; o < n_obs; ++o) {
                 const double *c = aabbs + 6 * o;          // uniform address: scalar loads
                 const bool hit = (px >= c[0]) && (px <= c[1]) && (py >= c[2]) && (py <= c[3]) && (pz >= c[4]) &&
@@ -313,7 +330,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     state[23 * sB + b] = pc; state[24 * sB + b] = qc; state[25 * sB + b] = rc;
     istate[0 * sB + b] = idx;
     istate[1 * sB + b] = inner;
-    istate[2 * sB + b] = collided;
+    if (!(AABB && LOG_STATE && CW == 1)) istate[2 * sB + b] = collided;
 }
 
 __global__ void state_init_kernel(const VehK V, const double *__restrict__ positions, int B, int hover,
