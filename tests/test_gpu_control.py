@@ -469,6 +469,16 @@ def test_logged_rollout_beyond_one_launch_is_split_without_a_trace(eng):
     nolog = eng.fleet(eng.plan(wps, 3.0, 0.01))
     nolog.rollout(K)                                                          # one launch, no log: same states
     assert torch.equal(nolog.state, big.state)
+    # the same with the per-tick obstacle test (run by the store wave when there is a state log, by the compute wave
+    # otherwise): flags agree between the split logged run, the sub-batch and the unlogged single launch
+    boxes = np.array([[0.0, 30.0, 0.0, 7.0, -3.5, -2.5], [10.0, 12.0, 8.0, 14.0, -4.0, -2.0]])
+    f_big, f_small, f_nolog = (eng.fleet(eng.plan(w, 3.0, 0.01)) for w in (wps, wps[cut:], wps))
+    f_big.rollout(K, state_log=True, aabbs=boxes)
+    f_small.rollout(K, state_log=True, aabbs=boxes)
+    f_nolog.rollout(K, aabbs=boxes)
+    assert torch.equal(f_big.collided[cut:], f_small.collided) and torch.equal(f_big.collided, f_nolog.collided)
+    assert 0 < int(f_big.collided.sum()) < B
+    assert torch.equal(f_big.state, f_nolog.state)
 
 
 def test_plan_fed_rollout_equals_row_fed_rollout(eng):
