@@ -1,0 +1,64 @@
+/*
+ * The C ABI from plain C: plan one mission through five waypoints (minimum snap), fly it with the cascaded
+ * controller + free-body dynamics, print where the vehicle ends up.  No Python, no torch: only include/uavac.h and
+ * libuavac.so (host-pointer entry points; the library stages through device memory itself).
+ *
+ *   gcc examples/c_abi_demo.c -Iinclude -Luav-autonomous-control_amd/lib -luavac \
+ *       -Wl,-rpath,$PWD/uav-autonomous-control_amd/lib -lm -o c_abi_demo && ./c_abi_demo
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "uavac.h"
+
+#define CHECK(call)                                                                                   \
+    do {                                                                                              \
+        int rc_ = (call);                                                                             \
+        if (rc_ != UAVAC_OK) {                                                                        \
+            fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, ctx ? uavac_last_error(ctx) : "");    \
+            return 1;                                                                                 \
+        }                                                                                             \
+    } while (0)
+
+int main(void) {
+    /* the five waypoints of the laboratory course's first leg (NED, metres) */
+    const double wp[5][3] = {{1, 7, -1.3}, {4, 7, -1.3}, {7.5, 4, -3}, {11, 7, -3.5}, {14, 10, -2.5}};
+    const int B = 1, m = 4;
+    const double velocity = 2.0, dt = 0.01;
+    uavac_ctx *ctx = NULL;
+    CHECK(uavac_create(&ctx, -1));
+
+    double times[4];
+    int32_t seg_rows[4];
+    int64_t offs[2];
+    CHECK(uavac_minsnap_row_counts(ctx, &wp[0][0], B, m, velocity, dt, times, seg_rows, offs));
+    double *coeffs = malloc(sizeof(double) * 24 * m);
+    double *traj = malloc(sizeof(double) * UAVAC_TRAJ_COLS * (size_t)offs[1]);
+    CHECK(uavac_minsnap_solve(ctx, &wp[0][0], B, m, velocity, coeffs, NULL));
+    CHECK(uavac_minsnap_sample(ctx, coeffs, times, B, m, dt, offs, traj));
+
+    uavac_vehicle V;
+    uavac_vehicle_default(&V);
+    double state[UAVAC_STATE_ROWS];            /* [26][B] with B = 1 */
+    int32_t istate[UAVAC_ISTATE_ROWS];
+    CHECK(uavac_state_init(ctx, &V, &wp[0][0], B, /*hover=*/1, state, istate));
+    const int K = (int)offs[1] * V.inner_per_outer + 2000;          /* the whole trajectory + 2 s to settle */
+    double *log = malloc(sizeof(double) * 13 * (size_t)K);          /* [K][13][B] */
+    CHECK(uavac_control_rollout(ctx, &V, traj, offs, state, istate, B, K, log, NULL, NULL, 0));
+
+    const double *last_row = traj + UAVAC_TRAJ_COLS * (size_t)(offs[1] - 1);
+    const double miss = sqrt(pow(state[0] - last_row[0], 2) + pow(state[1] - last_row[1], 2) + pow(state[2] - last_row[2], 2));
+    double worst = 0.0;
+    for (int64_t r = 0; r < offs[1]; ++r) {                         /* tracking error on every outer tick */
+        const double *x = log + 13 * (size_t)(r * V.inner_per_outer), *t = traj + UAVAC_TRAJ_COLS * (size_t)r;
+        const double e = sqrt(pow(x[0] - t[0], 2) + pow(x[1] - t[1], 2) + pow(x[2] - t[2], 2));
+        if (e > worst) worst = e;
+    }
+    printf("rows %lld, ticks %d, final position (%.3f, %.3f, %.3f), %.4f m from the last row, worst tracking error %.4f m, cursor %d\n",
+           (long long)offs[1], K, state[0], state[1], state[2], miss, worst, (int)istate[0]);
+    free(coeffs); free(traj); free(log);
+    uavac_destroy(ctx);
+    return miss < 0.05 && worst < 0.5 ? 0 : 2;
+}

@@ -80,3 +80,28 @@ def test_shard_bounds_partition_the_batch():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    from conftest import PKG, REPO
+    exe = str(tmp_path / "c_abi_demo")
+    lib_dir = os.path.join(PKG, "lib")
+    subprocess.run(["gcc", os.path.join(REPO, "examples", "c_abi_demo.c"), "-I" + os.path.join(REPO, "include"), "-L" + lib_dir,
+                    "-luavac", "-Wl,-rpath," + lib_dir, "-lm", "-Wall", "-Werror", "-o", exe], check=True, capture_output=True)
+    return exe
+
+
+def test_c_program_links_against_the_abi(tmp_path):
+    """examples/c_abi_demo.c -- plain C, only include/uavac.h and libuavac.so -- compiles without warnings and links."""
+    from uav_ac import _native as nat
+    nat.lib()                                          # builds libuavac.so if it is not there yet
+    assert os.path.exists(_build_c_demo(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_program_plans_and_flies_a_mission(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "worst tracking error" in out.stdout
