@@ -545,3 +545,45 @@ def test_plan_fed_rollout_corner_shapes(eng, nat, m, velocity, dt, F):
     _, c1 = only_cmd_a.rollout(300, cmd_log=True)
     _, c2 = only_cmd_b.rollout(300, cmd_log=True)
     assert torch.equal(c1, c2)
+
+
+def test_two_contexts_in_two_threads_do_not_disturb_each_other(nat):
+    """include/uavac.h: a ctx is not thread-safe, distinct ctxs are independent.  Two host threads, each with its own
+    context (own HIP stream), plan and fly different missions at the same time through the host-pointer entry points;
+    each gets exactly what it gets alone."""
+    import threading
+    from oracle import minsnap_oracle as mo
+
+    def job(ctx, seed, out):
+        wps = mo.synthetic_missions(48, 3 + seed)[seed::2][:16].copy()
+        B, m = wps.shape[0], wps.shape[1] - 1
+        times = np.empty((B, m)); seg_rows = np.empty((B, m), np.int32); offs = np.empty(B + 1, np.int64)
+        ctx.call("uavac_minsnap_row_counts", nat.np_ptr(wps), B, m, 3.0, 0.01, nat.np_ptr(times), nat.np_ptr(seg_rows), nat.np_ptr(offs))
+        coeffs = np.empty((B, 8 * m, 3))
+        ctx.call("uavac_minsnap_solve", nat.np_ptr(wps), B, m, 3.0, nat.np_ptr(coeffs), None)
+        traj = np.empty((int(offs[-1]), 11))
+        ctx.call("uavac_minsnap_sample", nat.np_ptr(coeffs), nat.np_ptr(times), B, m, 0.01, nat.np_ptr(offs), nat.np_ptr(traj))
+        V = nat.Vehicle.default()
+        state = np.empty((nat.STATE_ROWS, B)); istate = np.empty((nat.ISTATE_ROWS, B), np.int32)
+        ctx.call("uavac_state_init", C.byref(V), nat.np_ptr(np.ascontiguousarray(wps[:, 0, :])), B, 1, nat.np_ptr(state), nat.np_ptr(istate))
+        log = np.empty((400, 13, B))
+        for _ in range(3):
+            ctx.call("uavac_control_rollout", C.byref(V), nat.np_ptr(traj), nat.np_ptr(offs), nat.np_ptr(state), nat.np_ptr(istate),
+                     B, 400, nat.np_ptr(log), None, None, 0)
+        out[seed] = (traj, state.copy(), log.copy())
+
+    ctxs = [nat.Context(0), nat.Context(0)]
+    alone, together = {}, {}
+    for s in (0, 1):
+        job(ctxs[s], s, alone)
+    threads = [threading.Thread(target=job, args=(ctxs[s], s, together)) for s in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s in (0, 1):
+        for a, b in zip(alone[s], together[s]):
+            assert np.array_equal(a, b)
+    assert not np.array_equal(alone[0][1], alone[1][1])
+    for c in ctxs:
+        c.close()
