@@ -387,3 +387,40 @@ def test_reference_unit_tests_tree_bookkeeping(rrt_object):
     rrt_object.tree = {"[0.0, 0.0, 2.0]": start, "[0.0, 3.0, 0.0]": start}
     rrt_object._update_tree(np.array([0., 3., 0.]), np.array([0., 0., 2.]))
     assert np.all(rrt_object.tree["[0.0, 0.0, 2.0]"] == start)
+
+
+def test_rrt_entry_points_reject_bad_arguments():
+    """Negative UAVAC_E* codes with a message, never a crash: sizes < 1, null pointers, a non-positive step,
+    non-finite host inputs."""
+    import ctypes as C
+    from uav_ac import _native as nat
+    ctx = nat.Context(0)
+    lib = nat.lib()
+    P = nat.np_ptr
+    s = np.zeros((1, 3)); g = np.ones((1, 3)); smp = np.zeros((1, 4, 3)); cap = 5
+    nodes = np.empty((1, cap, 3)); path = np.empty((1, cap, 3))
+    canon = np.empty((1, cap), np.int32); par = np.empty((1, cap), np.int32); bpar = np.empty((1, cap), np.int32)
+    counts = np.empty((1, 6), np.int32); cost = np.empty(1)
+    outs = (P(nodes), P(canon), P(par), P(bpar), P(path), P(counts), P(cost))
+
+    def call(*a):
+        return lib.uavac_rrt_star(ctx._h, *a)
+    assert call(P(s), P(g), 1, 1.0, 4, P(smp), None, 0, *outs) == nat.OK
+    assert call(P(s), P(g), 0, 1.0, 4, P(smp), None, 0, *outs) == nat.EINVAL
+    assert call(P(s), P(g), 1, 1.0, 0, P(smp), None, 0, *outs) == nat.EINVAL
+    assert call(P(s), P(g), 1, 0.0, 4, P(smp), None, 0, *outs) == nat.EINVAL
+    assert call(P(s), P(g), 1, 1.0, 4, P(smp), None, 2, *outs) == nat.EINVAL          # obstacles announced, none given
+    assert call(None, P(g), 1, 1.0, 4, P(smp), None, 0, *outs) == nat.EINVAL
+    assert b"" != lib.uavac_last_error(ctx._h)
+    bad = smp.copy(); bad[0, 2, 1] = np.nan
+    assert call(P(s), P(g), 1, 1.0, 4, P(bad), None, 0, *outs) == nat.ENONFINITE
+    hit = np.empty(2, np.int32)
+    assert lib.uavac_rrt_segment_hits(ctx._h, P(np.zeros((2, 3))), P(np.ones((2, 3))), -1, None, 0, P(hit)) == nat.EINVAL
+    assert lib.uavac_rrt_segment_hits(ctx._h, P(np.zeros((2, 3))), P(np.ones((2, 3))), 2, None, 1, P(hit)) == nat.EINVAL
+    assert lib.uavac_rrt_segment_hits(ctx._h, P(np.zeros((2, 3))), P(np.ones((2, 3))), 0, None, 0, P(hit)) == nat.OK
+    out = np.empty(1)
+    assert lib.uavac_rrt_path_cost(ctx._h, None, 3, P(out)) == nat.EINVAL
+    assert lib.uavac_rrt_path_cost(ctx._h, None, 0, P(out)) == nat.OK and out[0] == 0.0
+    lens = np.array([9], np.int32); outp = np.empty((1, cap, 3)); outl = np.empty(1, np.int32)
+    assert lib.uavac_rrt_simplify(ctx._h, P(path), P(lens), 1, cap, None, 0, P(outp), P(outl)) == nat.EINVAL   # longer than cap
+    ctx.close()
