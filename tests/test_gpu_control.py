@@ -587,3 +587,25 @@ def test_two_contexts_in_two_threads_do_not_disturb_each_other(nat):
     assert not np.array_equal(alone[0][1], alone[1][1])
     for c in ctxs:
         c.close()
+
+
+def test_plan_fed_entry_points_reject_bad_arguments(eng, nat):
+    import torch
+    from oracle import minsnap_oracle as mo
+    plan = eng.plan(mo.synthetic_missions(8, 2), 3.0, 0.01)
+    fleet = eng.fleet(plan, from_plan=True)
+    lib, h, V = nat.lib(), eng.ctx._h, C.byref(fleet.vehicle)
+    P = lambda t: C.c_void_p(t.data_ptr())                  # noqa: E731
+    good = (P(plan.coeffs), P(plan.seg_rows), P(plan.row_offsets), P(plan.yaw), plan.m, plan.dt, P(fleet.state), P(fleet.istate), 8, 5,
+            None, None, None, 0)
+
+    def call(*a):
+        return lib.uavac_control_rollout_plan_dev(h, V, *a)
+    assert call(*good) == nat.OK
+    for i, bad in ((0, None), (1, None), (3, None), (4, 0), (4, 65), (5, 0.0), (5, float("nan")), (6, None), (8, 0), (9, -1), (13, -2)):
+        args = list(good); args[i] = bad
+        assert call(*args) == nat.EINVAL, i
+    assert call(*(good[:9] + (0,) + good[10:])) == nat.OK            # K = 0: nothing to do
+    assert lib.uavac_minsnap_sample_yaw_dev(h, P(plan.coeffs), P(plan.times), P(plan.seg_rows), P(plan.row_offsets), 8, 2, 0.01,
+                                            P(plan.traj), None) == nat.EINVAL
+    torch.cuda.synchronize()
