@@ -6,25 +6,33 @@ controller + dynamics ticks, on synthetic missions (SURVEY.md 8(d) generator).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one whole job over one batch: times/row counts + coefficient solve + sampler (once per
-mission), vehicle reset, then 10 000 control ticks as 10 launches of 1 000 ticks whose 6.8 GB state
-log buffer is reused.  Inputs (waypoints) are resident in HBM before the timed region.  The batch
-shards by mission index over ranks with no data-path collective (weak scaling: 65 536 UAVs per
-GPU); the final gather of trajectories to rank 0 over RCCL is timed separately (`gather_ms`).
+A "step" is one whole job over one batch: the planning chain (times/row counts, offsets, coefficient solve,
+sampler; ONE call into the C ABI), vehicle reset, then 10 000 control ticks as 10 launches of 1 000 ticks whose
+6.8 GB state log buffer is reused.  Inputs (waypoints) are resident in HBM before the timed region.  The batch
+shards by mission index over ranks with no data-path collective (weak scaling: 65 536 UAVs per GPU).
 
-Prints ONE JSON line on rank 0.  `value` = UAV control ticks of all ranks / wall time of the K timed
-steps (planning time included in the denominator).  `roofline` prices the dominant kernel
-(control_rollout) against the HBM peak with the algorithmic 112.8 B per UAV tick of SURVEY.md 8(d);
-`cpu_baseline` is the CPU oracle timed on this box's host cores on a bounded sample.
+Prints ONE JSON line on rank 0.  `value` = UAV control ticks of all ranks / wall time of the K timed steps
+(planning time included in the denominator).  `roofline` prices the dominant kernel (control_rollout) against
+the HBM peak with the algorithmic 112.8 B per UAV tick of SURVEY.md 8(d), on the average launch duration
+measured with HIP events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle timed
+on this box's host cores on a bounded sample.  `config4` is BASELINE.json configs[3] run on the same N GPUs
+(262 144 UAVs in total = strong scaling, 8-segment missions, 5 000 ticks, final gather of the trajectories to
+rank 0 over RCCL timed and verified) with compute-only and compute+gather rates side by side.
+
+Exit status: 0 only when everything asked for ran; a stalled or failed gather prints the line with
+`gather_error` and exits 3.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")):
+PKG = os.path.join(ROOT, "uav-autonomous-control_amd")
+for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -36,12 +44,10 @@ SEGMENTS = 12
 TICKS = 10000
 CHUNK = 1000
 VELOCITY, DT, F = 3.0, 0.01, 10
-# fp64 VALU instructions one lane executes per tick in control_rollout_kernel<1,true,false,false>, counted in the
-# gfx950 ISA of the small-angle path every tick takes (207 in the per-tick body + 377 in the outer block / F);
-# priced against the vector fp64 peak of MI355X_MICROARCH.md (78.6 TFLOP/s = 39.3 T lane-FMA/s).
-FP64_VALU_PER_TICK = 245
-FP64_LANE_INSTR_PEAK = 39.3e12
+FP64_LANE_INSTR_PEAK = 39.3e12  # vector fp64 peak of MI355X_MICROARCH.md: 78.6 TFLOP/s = 39.3 T lane-FMA/s
 GATHER_TIMEOUT_S = 240
+C4_TOTAL, C4_SEGMENTS, C4_TICKS = 262144, 8, 5000           # BASELINE.json configs[3]
+ROLLOUT_SOURCES = ("csrc/control_rollout.hip", "csrc/control_law.h", "csrc/minsnap_eval.h", "csrc/uavac_internal.h")
 
 
 def missions(B_total, m, lo, hi):
@@ -53,6 +59,31 @@ def missions(B_total, m, lo, hi):
     w0 = np.concatenate([rng.uniform(0, 24, (B_total, 1, 1)), rng.uniform(0, 14, (B_total, 1, 1)),
                          np.full((B_total, 1, 1), -3.0)], axis=2)
     return np.concatenate([w0, w0 + np.cumsum(L * d, axis=1)], axis=1)[lo:hi]
+
+
+def rollout_source_sha():
+    """Fingerprint of the sources the rollout kernel is compiled from.  Measurements kept under profiles/ (PMC
+    traffic, ISA instruction counts) carry it; the bench only quotes them while it still matches."""
+    h = hashlib.sha256()
+    for rel in ROLLOUT_SOURCES:
+        with open(os.path.join(PKG, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def kept_measurement(name, key, kernel=None):
+    """A number measured by tools/ (pmc_traffic.py, count_valu.py) and committed under profiles/, or None when the
+    kernel sources have changed since (or the file is for another kernel)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if rec.get("rollout_source_sha") != rollout_source_sha():
+        return None
+    if kernel is not None and rec.get("kernel") not in (None, kernel):
+        return None
+    return rec.get(key)
 
 
 def cpu_baseline(eng=None, wps=None):
@@ -93,56 +124,46 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="UAVs per GPU (default: config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed diagnostic passes (per-launch table, "
+                                                             "flyable-distribution rate)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from uav_ac.fleet import Engine, Fleet, gather_rows
+    from uav_ac.fleet import Engine, Fleet, RcclComm
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # UAVAC_BENCH_BACKEND=gloo is a rehearsal switch: it lets several ranks share one GPU (RCCL refuses that), so
-    # the N > 1 control flow can be exercised on a 1-GPU box.  The driver's runs use nccl (= RCCL), one GPU per rank.
-    backend = os.environ.get("UAVAC_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("nccl", device_id=dev)          # barrier + max-over-ranks only; the gather has its own comm
 
     B, m = args.batch, SEGMENTS
     eng = Engine(dev)
     wps = missions(B * world, m, rank * B, (rank + 1) * B)
     plan = eng.plan(wps, VELOCITY, DT)                   # allocates; also the first warm-up
-    eng.check(plan)
     fleet = eng.fleet(plan)
     log = torch.empty((CHUNK, 13, B), dtype=torch.float64, device=dev)
     n_chunks = TICKS // CHUNK
     ev = lambda: torch.cuda.Event(enable_timing=True)    # noqa: E731  (torch's current stream = the ctx's stream)
 
     def one_step(record=None):
-        e0, e1 = ev(), ev()
+        e0, e1, e2 = ev(), ev(), ev()
         e0.record()
-        eng.solve(plan)
-        eng.sample(plan)
+        eng.replan(plan)                                 # 4 launches enqueued by one C call
         e1.record()
         fleet.reset()
-        pairs = []
         for _ in range(n_chunks):
-            a, b = ev(), ev()
-            a.record()
             fleet.rollout(CHUNK, state_log=log)
-            b.record()
-            pairs.append((a, b))
+        e2.record()
         if record is not None:
-            record.append(((e0, e1), pairs))
+            record.append((e0, e1, e2))
 
     def barrier():
         torch.cuda.synchronize()
@@ -163,16 +184,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    flags = eng.take_flags()
+    assert flags == [0, 0, 0, 0], f"planning flags raised: {flags}"
 
-    plan_ms = [a.elapsed_time(b) for (a, b), _ in rec]
-    roll_ms = [a.elapsed_time(b) for _, pairs in rec for a, b in pairs]
-    roll_avg_s = float(np.mean(roll_ms)) * 1e-3
+    plan_ms = [a.elapsed_time(b) for a, b, _ in rec]
+    # e1 -> e2 spans reset (a 5 us kernel) + the n_chunks rollout launches (each preceded by its ~2 us aligner launch);
+    # their share is part of the average on purpose: it is what a launch costs in the job
+    roll_avg_s = float(np.mean([b.elapsed_time(c) for _, b, c in rec])) * 1e-3 / n_chunks
     plan_avg_s = float(np.mean(plan_ms)) * 1e-3
+    kernel_name = eng.ctx.last_rollout_kernel()
 
-    # sanity inside the bench: after TICKS ticks every cursor must sit at min(TICKS/F, rows-1) exactly, and
-    # the share of UAVs within the reference's 0.5 m acceptance of their current target row is reported.
-    # (The reference controller itself loses about 1 in 7 of the 8(d) missions -- the CPU oracle loses the
-    # same lanes, tests/test_gpu_control.py -- the work per tick is identical either way.)
+    # sanity inside the bench: after TICKS ticks every cursor must sit at min(TICKS/F, rows-1) exactly; the share of
+    # UAVs within the reference's 0.5 m acceptance of their current target row is reported, and so is the state of the
+    # others: the reference law itself loses about 1 in 7 of the 8(d) missions (3 m legs with random turns at 3 m/s;
+    # the CPU oracle loses the same lanes, tests/test_gpu_control.py) -- do they go non-finite, do they leave the
+    # small-angle branch of the attitude update (|w| dt / 2 > 0.0316, control_law.h), i.e. do they cost more per tick?
     nrows = plan.row_offsets[1:] - plan.row_offsets[:-1]
     idx = fleet.trajectory_index.long()
     cursor_ok = bool((idx == torch.clamp(torch.full_like(nrows, TICKS // F), max=nrows - 1)).all())
@@ -180,7 +206,16 @@ def main():
     track = (fleet.X[0:3] - target).norm(dim=0)
     kept = track < 0.5
     frac_kept = float(kept.double().mean())
-    finite_kept = bool(torch.isfinite(fleet.state[:, kept]).all())
+    lane_finite = torch.isfinite(fleet.state).all(dim=0)
+    body_rate = fleet.X[10:13].norm(dim=0)
+    large_angle = body_rate * (0.5 * fleet.vehicle.dt) > 0.0316
+    checks = {"frac_uavs_within_0.5m_of_target_row": frac_kept,
+              "tracking_lanes_finite": bool(lane_finite[kept].all()),
+              "all_trajectory_cursors_exact": cursor_ok,
+              "lanes_nonfinite_at_end": int((~lane_finite).sum()),
+              "lanes_in_large_angle_branch_at_end": int((large_angle & lane_finite).sum()),
+              "max_body_rate_rad_s_at_end": float(body_rate[lane_finite].max()),
+              "planning_flags": flags}
 
     out = None
     if rank == 0:
@@ -188,11 +223,9 @@ def main():
         value = total_ticks / elapsed
         roll_bytes = Fleet.algorithmic_bytes(B, CHUNK, F)
         achieved = roll_bytes / roll_avg_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and B == B_PER_GPU:
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("control_rollout_bytes_per_launch")
+        same_size = B == B_PER_GPU
+        traffic = kept_measurement("hbm_traffic.json", "control_rollout_bytes_per_launch", kernel_name) if same_size else None
+        valu = kept_measurement("rollout_isa_count.json", "fp64_valu_per_tick", kernel_name)
         out = {
             "metric": "UAV control-steps/sec at batch=65536",
             "value": value,
@@ -212,13 +245,12 @@ def main():
                        "batch_per_gpu": B, "segments": m, "ticks": TICKS, "ticks_per_launch": CHUNK,
                        "velocity": VELOCITY, "dt": DT, "inner_per_outer": F, "rows": plan.total_rows,
                        "parallelism": f"missions sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "control_rollout_kernel<1, true, false, false, true>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("profiles/hbm_traffic.json (tools/pmc_traffic.py; same kernel sources)"
+                                            if traffic is not None else None),
                          "algorithmic_bytes_per_launch": roll_bytes, "avg_launch_ms": roll_avg_s * 1e3,
-                         "fp64_valu": {"lane_instr_per_tick": FP64_VALU_PER_TICK,
-                                       "achieved": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s,
-                                       "peak": FP64_LANE_INSTR_PEAK, "unit": "fp64 lane-instr/s",
-                                       "frac": B * CHUNK * FP64_VALU_PER_TICK / roll_avg_s / FP64_LANE_INSTR_PEAK}},
+                         "rollout_source_sha": rollout_source_sha()},
             "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
                         "ms_solve_plus_sample": plan_avg_s * 1e3,
                         "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
@@ -228,51 +260,148 @@ def main():
             "rollout_only": {"value": B * CHUNK / roll_avg_s, "unit": "UAV control-steps/s per GPU",
                              "note": "SURVEY 8(d)(i): B x K / time of the rollout launches alone (`value` above also "
                                      "carries the planning time of every step)"},
-            "checks": {"frac_uavs_within_0.5m_of_target_row": frac_kept, "tracking_lanes_finite": finite_kept,
-                       "all_trajectory_cursors_exact": cursor_ok},
+            "checks": checks,
         }
+        if valu is not None:
+            rate = B * CHUNK * valu / roll_avg_s
+            out["roofline"]["fp64_valu"] = {"lane_instr_per_tick": valu, "achieved": rate, "peak": FP64_LANE_INSTR_PEAK,
+                                            "unit": "fp64 lane-instr/s", "frac": rate / FP64_LANE_INSTR_PEAK,
+                                            "source": "profiles/rollout_isa_count.json (tools/count_valu.py)"}
 
-    # final gather of the sampled trajectories to rank 0 (north_star: the only collective).  The timed result is
-    # complete before it starts; a watchdog makes sure the result line still gets printed if the exchange stalls.
-    gather_ms, gather_err = None, None
-    if world > 1:
-        import threading
+    # ---- untimed diagnostics: per-launch durations of one more step, and the rollout on a flyable distribution -------
+    if not args.no_extras:
+        eng.replan(plan)
+        fleet.reset()
+        pairs = []
+        for _ in range(n_chunks):
+            a, b = ev(), ev()
+            a.record()
+            fleet.rollout(CHUNK, state_log=log)
+            b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        per_launch = [a.elapsed_time(b) for a, b in pairs]
+        # the same missions flown at half the speed (velocity 1.5: legs demand < 2.5 m/s^2): nobody departs
+        slow = eng.plan(wps, VELOCITY / 2, DT)
+        fl2 = eng.fleet(slow)
+        a, b = ev(), ev()
+        for _ in range(2):
+            fl2.rollout(CHUNK, state_log=log)
+        a.record()
+        for _ in range(n_chunks):
+            fl2.rollout(CHUNK, state_log=log)
+        b.record()
+        torch.cuda.synchronize()
+        idx2 = fl2.trajectory_index.long()
+        tgt2 = slow.traj[slow.row_offsets[:-1] + idx2, 0:3].T
+        kept2 = float(((fl2.X[0:3] - tgt2).norm(dim=0) < 0.5).double().mean())
+        if rank == 0:
+            out["roofline"]["per_launch_ms_one_step"] = [round(x, 4) for x in per_launch]
+            out["rollout_only_flyable"] = {"value": B * CHUNK * n_chunks / (a.elapsed_time(b) * 1e-3),
+                                           "unit": "UAV control-steps/s per GPU", "velocity": VELOCITY / 2,
+                                           "frac_uavs_within_0.5m_of_target_row": kept2,
+                                           "note": "same missions at half the cruise speed, where the reference law "
+                                                   "keeps every UAV on its trajectory"}
+        del slow, fl2
 
-        def bail():
-            if rank == 0:
-                out["gather_error"] = f"no completion within {GATHER_TIMEOUT_S} s"
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(GATHER_TIMEOUT_S, bail)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            barrier()
-            g0 = time.perf_counter()
-            gathered, counts = gather_rows(plan.traj, dst=0)
-            barrier()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            if rank == 0 and (sum(counts) != gathered.shape[0] or not bool((gathered[:plan.total_rows] == plan.traj).all())):
-                gather_err = "gathered rows do not match"
-            del gathered
-        except Exception as exc:                      # the timed result above must survive a collective problem
-            gather_err = f"{type(exc).__name__}: {exc}"
-        watchdog.cancel()
+    # ---- BASELINE configs[3] on the same N GPUs: 262 144 UAVs in total, m = 8, 5 000 ticks, gather to rank 0 ----------
+    gather_err = None
+    comm = None
+    if not args.no_config4:
+        del plan, fleet, log
+        torch.cuda.empty_cache()
+        B4 = C4_TOTAL // world
+        wps4 = missions(C4_TOTAL, C4_SEGMENTS, rank * B4, (rank + 1) * B4)
+        plan4 = eng.plan(wps4, VELOCITY, DT)
+        fleet4 = eng.fleet(plan4)
+        log4 = torch.empty((CHUNK, 13, B4), dtype=torch.float64, device=dev)
+
+        def step4():
+            eng.replan(plan4)
+            fleet4.reset()
+            for _ in range(C4_TICKS // CHUNK):
+                fleet4.rollout(CHUNK, state_log=log4)
+
+        step4()
+        barrier()
+        n4 = 3
+        t0 = time.perf_counter()
+        for _ in range(n4):
+            step4()
+        barrier()
+        c4_compute = (time.perf_counter() - t0) / n4
+        if world > 1:
+            t = torch.tensor([c4_compute], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c4_compute = float(t.item())
+        c4 = {"workload": "BASELINE.json configs[3]: 262144 UAVs in total (strong scaling), 8-segment missions, plan + "
+                          "5000 fused ticks (5 launches x 1000, state logged), trajectories gathered to rank 0",
+              "batch_total": C4_TOTAL, "batch_per_gpu": B4, "segments": C4_SEGMENTS, "ticks": C4_TICKS,
+              "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
+              "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel()}
+        if rank == 0:
+            out["config4"] = c4
+
+        if world > 1:
+            def bail():
+                # a stalled exchange must not lose the measurement -- and must not look like a success either
+                if rank == 0:
+                    out["gather_error"] = f"no completion within {GATHER_TIMEOUT_S} s"
+                    print(json.dumps(out), flush=True)
+                os._exit(3)
+            watchdog = threading.Timer(GATHER_TIMEOUT_S, bail)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                comm = RcclComm(eng)                       # ncclCommInitRank behind the C ABI; id travels over the process group
+                comm.gather_rows(plan4.traj[:1024], dst=0)      # connection set-up is not part of the timed gather
+                barrier()
+                g0 = time.perf_counter()
+                gathered, counts = comm.gather_rows(plan4.traj, dst=0)
+                barrier()
+                gather_s = time.perf_counter() - g0
+                if rank == 0:
+                    ok = sum(counts) == gathered.shape[0] and bool((gathered[:plan4.total_rows] == plan4.traj).all())
+                    # every peer's block starts with its first mission's first waypoint, at rest
+                    offs = np.concatenate([[0], np.cumsum(counts)])
+                    first = missions(C4_TOTAL, C4_SEGMENTS, 0, C4_TOTAL)[::B4, 0, :]
+                    got = gathered[torch.as_tensor(offs[:-1], device=dev), 0:3].cpu().numpy()
+                    ok = ok and bool(np.array_equal(got, first))
+                    if not ok:
+                        gather_err = "gathered rows do not match"
+                    c4.update({"gather_ms": gather_s * 1e3, "gather_rows_total": int(sum(counts)),
+                               "gather_GBps_into_root": (sum(counts) - counts[0]) * 88 / gather_s / 1e9,
+                               "steps_per_s_with_gather": C4_TOTAL * C4_TICKS / (c4_compute + gather_s),
+                               "gather_verified": ok})
+                del gathered
+            except Exception as exc:                      # the timed result above must survive a collective problem
+                gather_err = f"{type(exc).__name__}: {exc}"
+            watchdog.cancel()
 
     def leave():
         if world > 1:
             if gather_err is None:
+                if comm is not None:
+                    comm.close()
                 dist.destroy_process_group()
             else:                                     # a communicator that failed once may not shut down cleanly
                 sys.stdout.flush()
-                os._exit(0)
+                os._exit(3)
+        if gather_err is not None:
+            sys.exit(3)
+
+    if world > 1:                                     # every rank learns whether any rank failed
+        bad = torch.tensor([0 if gather_err is None else 1], dtype=torch.int32, device=dev)
+        try:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()) and gather_err is None:
+                gather_err = "gather failed on another rank"
+        except Exception as exc:
+            gather_err = gather_err or f"{type(exc).__name__}: {exc}"
 
     if rank != 0:
         leave()
         return
-    if gather_ms is not None:
-        out["gather_ms"] = gather_ms
-        out["gather_GBps_into_root"] = (world - 1) * plan.total_rows * 88 / (gather_ms * 1e-3) / 1e9
     if gather_err is not None:
         out["gather_error"] = gather_err
     if world == 1 and not args.no_cpu_baseline:

@@ -37,6 +37,7 @@ extern "C" {
 #define UAVAC_EHIP (-3)      /* HIP runtime error (text in uavac_last_error)       */
 #define UAVAC_ESINGULAR (-4) /* a mission's knot system is singular (e.g. repeated waypoint) */
 #define UAVAC_ENOMEM (-5)
+#define UAVAC_ECOMM (-6)     /* RCCL error (text in uavac_last_error)              */
 
 #define UAVAC_MAX_SEGMENTS 64   /* m, segments per mission                          */
 #define UAVAC_TRAJ_COLS 11      /* x y z vx vy vz ax ay az yaw spline_id: minimum_snap.py:122-123 */
@@ -79,6 +80,26 @@ const char *uavac_last_error(const uavac_ctx *ctx);
 int uavac_set_stream(uavac_ctx *ctx, void *hip_stream);
 int uavac_reset_stream(uavac_ctx *ctx);
 int uavac_synchronize(uavac_ctx *ctx);
+/* The HIP device the ctx was created for.  Every entry point makes that device current for its own
+ * duration and restores the caller's: a ctx for GPU 1 works while GPU 0 is the thread's device. */
+int uavac_device(const uavac_ctx *ctx);
+/* Name and template arguments <compute waves, store waves, state log, command log, obstacle test,
+ * plan-fed> of the rollout kernel the ctx launched last ("" before the first): what a profile of
+ * the same call will show.  Diagnostics for benchmarks; the string lives in the ctx. */
+const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
+/* Tuning knobs; results never depend on them (tested bit for bit).  "rollout_shape": workgroup
+ * shape of rollout launches that write a log -- 1 = one compute + one store wave per 64 UAVs,
+ * 4 = four + four per 256 UAVs for full-chip launches (65 536 columns).  "rollout_align": 1 = precede
+ * a shape-1 logged launch by an empty kernel of the same workgroup shape, which makes the hardware
+ * place one compute and one store wave on every SIMD whatever ran before.
+ * Defaults from the environment (UAVAC_ROLLOUT_SHAPE, UAVAC_ROLLOUT_ALIGN) at uavac_create. */
+int uavac_set_option(uavac_ctx *ctx, const char *name, int value);
+/* The _dev planning entry points report data-dependent failures through sticky device-side flags
+ * instead of synchronising: flags[0] non-finite segment duration, flags[1] singular knot system,
+ * flags[2] trajectory buffer too small (uavac_minsnap_plan_dev), flags[3] a mission with more than
+ * 2^31-1 rows.  This call synchronises the stream, returns them and clears them.  The host-pointer
+ * twins clear the flags on entry and turn them into UAVAC_E* return codes themselves. */
+int uavac_take_flags(uavac_ctx *ctx, int32_t flags[4]);
 /* Fill *V with the laboratory vehicle (lab_course.xml) and the gains of quad.py:42-73. */
 void uavac_vehicle_default(uavac_vehicle *V);
 
@@ -121,7 +142,33 @@ int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const do
                                   const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                                   double dt, double *traj, const double *aabb, int32_t *hit);
 
-/* Host-pointer twins (synchronous). */
+/* The sampler with every optional output: yaw [rows] (or NULL) as above; jerk / snap [rows][3] (or
+ * NULL) = polynom(8, 3, t) @ coeffs and polynom(8, 4, t) @ coeffs, the two samples the reference
+ * evaluates in comments only (minimum_snap.py:111-112,118-119).  They are separate arrays: the
+ * (N, 11) row layout of get_trajectory() never changes. */
+int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows,
+                                    const int64_t *row_offsets, int B, int m, double dt, double *traj,
+                                    double *yaw, double *jerk, double *snap);
+/* The whole planning chain of MinimumSnap.get_trajectory() (obstacles=None; minimum_snap.py:59-61,
+ * 97-124) enqueued by ONE call: times + row counts, row offsets, coefficient solve, sampler (+ yaw
+ * column when yaw != NULL) -- four kernel launches back to back, no host code in between.  The row
+ * buffer must have been sized by the caller: traj holds traj_capacity_rows rows (yaw as many
+ * values); when the plan needs more, nothing is written and flag 2 is raised (uavac_take_flags).
+ * Typical use: size the buffers once with uavac_minsnap_row_counts_dev, then re-plan in place. */
+int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
+                           double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs,
+                           int32_t *status, double *traj, int64_t traj_capacity_rows, double *yaw);
+/* MinimumSnap._calculate_yaws (minimum_snap.py:126-136) on its own, for B independent velocity
+ * sequences of any length: sequence b = rows [offsets[b], offsets[b+1]) of velocities[.][3] (only
+ * vx, vy are read); yaws[offsets[B]].  Headings of rows with |v_xy| >= 1e-3, np.unwrap over those,
+ * hold-last-valid, leading rows take the first valid heading, all zeros when none is valid. */
+int uavac_yaw_scan_dev(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B,
+                       double *yaws);
+/* Host twin for one sequence: velocities [n][3] -> yaws [n]. */
+int uavac_yaw_scan(uavac_ctx *ctx, const double *velocities, int64_t n, double *yaws);
+
+/* Host-pointer twins (synchronous).  They stage through device scratch and a pinned ping-pong
+ * buffer that the ctx keeps between calls (no allocation per call once warm). */
 int uavac_minsnap_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity,
                              double dt, double *times, int32_t *seg_rows, int64_t *row_offsets);
 int uavac_minsnap_solve(uavac_ctx *ctx, const double *wp, int B, int m, double velocity,
@@ -296,6 +343,40 @@ int uavac_rrt_steer_dev(uavac_ctx *ctx, const double *sample, const double *near
                         double step, double *out);
 int uavac_rrt_steer(uavac_ctx *ctx, const double *sample, const double *nearest, int E, double step,
                     double *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU.  One process per GPU, one ctx per process; missions are sharded by
+ * contiguous index blocks and every entry point above works on its own shard -- nothing is
+ * exchanged while planning or flying.  The ONE exchange of the path is the final gather of the
+ * ragged row blocks (trajectories, or any [n][row_elems] f64 block) to a root rank over RCCL:
+ * ncclGroupStart + ncclRecv per peer on the root / ncclSend on the peers + ncclGroupEnd
+ * (rccl.h:700,722,923), i.e. every peer uses its own direct xGMI link into the root at once.
+ * (No reference counterpart: upstream plans and flies one mission per process, main.py:87-120.)
+ *
+ * nccl_comm is an ncclComm_t (passed as void* so that this header does not need rccl.h): either the
+ * caller's own communicator or one made by uavac_comm_init_rank.  Bootstrap: rank 0 calls
+ * uavac_comm_unique_id and hands the 128 bytes to the other ranks by any side channel (environment,
+ * file, torch.distributed store); then every rank calls uavac_comm_init_rank (collective). */
+#define UAVAC_COMM_ID_BYTES 128
+int uavac_comm_unique_id(uavac_ctx *ctx, char id[UAVAC_COMM_ID_BYTES]);
+int uavac_comm_init_rank(uavac_ctx *ctx, const char id[UAVAC_COMM_ID_BYTES], int world, int rank,
+                         void **nccl_comm);
+int uavac_comm_destroy(uavac_ctx *ctx, void *nccl_comm);
+int uavac_comm_abort(uavac_ctx *ctx, void *nccl_comm);      /* after a failure or a timeout */
+int uavac_comm_shape(uavac_ctx *ctx, void *nccl_comm, int *world, int *rank);
+/* Every rank contributes its row count; counts [world] (HOST) receives all of them
+ * (ncclAllGather of one int64 per rank; synchronous). */
+int uavac_gather_counts(uavac_ctx *ctx, void *nccl_comm, int64_t n_rows, int64_t *counts);
+/* Gather: rank r's rows [counts[r]][row_elems] (device) land at row offset sum(counts[:r]) of out
+ * (device, root only: [sum(counts)][row_elems]; ignored elsewhere).  counts is the HOST array of
+ * uavac_gather_counts.  Enqueued on the ctx stream; uavac_comm_finish synchronises the stream and
+ * reports asynchronous RCCL errors. */
+int uavac_gather_rows_dev(uavac_ctx *ctx, void *nccl_comm, const double *rows, int64_t n_rows,
+                          int row_elems, const int64_t *counts, int root, double *out);
+int uavac_comm_finish(uavac_ctx *ctx, void *nccl_comm);
+/* Self-test of the transport on a single GPU: src [n] -> dst [n] through ncclSend + ncclRecv with
+ * this rank as its own peer, grouped exactly like the gather (enqueued; then uavac_comm_finish). */
+int uavac_comm_loopback_dev(uavac_ctx *ctx, void *nccl_comm, const double *src, double *dst, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -39,7 +39,9 @@ void oracle_times(const double *wp, int m, double velocity, double *times) { /* 
     for (int i = 0; i < m; ++i) {
         double dx = wp[3 * (i + 1)] - wp[3 * i], dy = wp[3 * (i + 1) + 1] - wp[3 * i + 1],
                dz = wp[3 * (i + 1) + 2] - wp[3 * i + 2];
-        double t = sqrt(dx * dx + dy * dy + dz * dz) / velocity;
+        /* np.linalg.norm of a 3-vector = sqrt(x.dot(x)); BLAS ddot accumulates with fused multiply-adds (see
+         * rrt_oracle.c).  Only this form reproduces the committed reference times bit for bit. */
+        double t = sqrt(fma(dz, dz, fma(dy, dy, dx * dx))) / velocity;
         if (i == 0 || i == m - 1) t *= 1.5;
         times[i] = t;
     }

@@ -47,7 +47,7 @@ def test_synthetic_missions_match_reference_golden(ctx, m):
     g = load_golden("synthetic_missions.npz")
     wps = g[f"m{m}_wp"]
     coeffs, times, seg_rows, offs, traj = host_plan(ctx, wps, 3.0, 0.01)
-    assert np.allclose(times, g[f"m{m}_times"], rtol=1e-14, atol=0)
+    assert np.array_equal(times, g[f"m{m}_times"])             # bit for bit: the FMA dot product of np.linalg.norm
     assert np.array_equal(seg_rows, g[f"m{m}_rows_per_segment"])          # row counts exact
     assert col_err(coeffs.reshape(-1, 3), g[f"m{m}_coeffs_lstsq"].reshape(-1, 3)) < TOL
     assert col_err(coeffs.reshape(-1, 3), g[f"m{m}_coeffs_solve"].reshape(-1, 3)) < 1e-9
@@ -66,7 +66,7 @@ def test_synthetic_missions_match_reference_golden(ctx, m):
 def test_config1_and_lab_missions_match_reference_golden(ctx):
     g = load_golden("fixed_missions.npz")
     coeffs, times, _, offs, traj = host_plan(ctx, g["config1_wp"][None], 3.0, 0.01)
-    assert np.allclose(times[0], g["config1_times"], rtol=1e-14, atol=0)
+    assert np.array_equal(times[0], g["config1_times"])
     assert traj.shape == (687, 11)
     assert col_err(coeffs[0], g["config1_coeffs"]) < TOL
     assert col_err(traj, g["config1_traj"]) < TOL

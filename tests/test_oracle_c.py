@@ -15,7 +15,7 @@ def test_c_planner_matches_reference_golden(m):
     sub = []
     for i, wp in enumerate(wps):
         traj, coeffs, times = cc.plan(wp, 3.0, 0.01)
-        assert np.allclose(times, g[f"m{m}_times"][i], rtol=1e-15, atol=0)
+        assert np.array_equal(times, g[f"m{m}_times"][i])          # bit for bit (FMA dot product of np.linalg.norm)
         assert np.array_equal(np.bincount(traj[:, 10].astype(int), minlength=m), g[f"m{m}_rows_per_segment"][i])
         assert col_err(coeffs, g[f"m{m}_coeffs_solve"][i]) < 1e-9
         assert col_err(coeffs, g[f"m{m}_coeffs_lstsq"][i]) < TOL

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Which "mode" is this box in?  Sampler time, plus clocks / power while it runs.
+hostname; rocm-smi --showuniqueid --showserial 2>/dev/null | grep -i "unique\|serial" | head -3
+python3 - <<'PY' &
+import os, sys, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", ".")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
+import torch
+from bench import missions
+from uav_ac.fleet import Engine
+eng = Engine("cuda:0")
+plan = eng.plan(missions(65536, 12, 0, 65536), 3.0, 0.01)
+t_end = time.time() + 6
+while time.time() < t_end:
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(200): eng.sample(plan)
+    b.record(); torch.cuda.synchronize()
+    print(f"sampler+yaw {a.elapsed_time(b)/200:.3f} ms", flush=True)
+PY
+sleep 4
+rocm-smi --showclocks --showpower --showperflevel 2>/dev/null | grep -v "^=\|^$" | head -30
+wait

@@ -1,0 +1,115 @@
+"""A/B of the planning kernels between two builds of libuavac.so on the same box, same buffers, alternating:
+the in-tree build against tools/ab/libuavac_r01.so (the round-1 library; build it from the round-1 commit with
+`git worktree add /tmp/old <commit> && make -C /tmp/old/uav-autonomous-control_amd`).  Also: how much the sampler's
+time depends on the allocation its rows land in (fresh buffers per repetition).
+
+    python3 tools/sampler_ab.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
+import numpy as np
+import torch
+from bench import missions
+
+B, M = 65536, 12
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+P = C.c_void_p
+
+
+def load(path):
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+    lib.uavac_create.argtypes = [C.POINTER(P), C.c_int]
+    lib.uavac_set_stream.argtypes = [P, P]
+    lib.uavac_minsnap_row_counts_dev.argtypes = [P, P, C.c_int, C.c_int, C.c_double, C.c_double, P, P, P]
+    lib.uavac_minsnap_solve_dev.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
+    lib.uavac_minsnap_sample_yaw_dev.argtypes = [P, P, P, P, P, C.c_int, C.c_int, C.c_double, P, P]
+    lib.uavac_minsnap_sample_dev.argtypes = [P, P, P, P, P, C.c_int, C.c_int, C.c_double, P]
+    h = P()
+    assert lib.uavac_create(C.byref(h), 0) == 0
+    assert lib.uavac_set_stream(h, P(torch.cuda.current_stream().cuda_stream)) == 0
+    return lib, h
+
+
+libs = {"new": load(os.path.join(ROOT, "uav-autonomous-control_amd", "lib", "libuavac.so")),
+        "r01": load(os.path.join(ROOT, "tools", "ab", "libuavac_r01.so"))}
+wp = torch.as_tensor(missions(B, M, 0, B), device=dev)
+kw = dict(device=dev)
+times = torch.empty((B, M), dtype=torch.float64, **kw)
+seg = torch.empty((B, M), dtype=torch.int32, **kw)
+ro = torch.empty((B + 1,), dtype=torch.int64, **kw)
+co = torch.empty((B, 8 * M, 3), dtype=torch.float64, **kw)
+st = torch.zeros((B,), dtype=torch.int32, **kw)
+p = lambda t: P(t.data_ptr())
+lib, h = libs["new"]
+assert lib.uavac_minsnap_row_counts_dev(h, p(wp), B, M, 3.0, 0.01, p(times), p(seg), p(ro)) == 0
+assert lib.uavac_minsnap_solve_dev(h, p(wp), p(times), B, M, p(co), p(st)) == 0
+N = int(ro[-1].item())
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+traj = torch.empty((N, 11), dtype=torch.float64, **kw)
+yaw = torch.empty((N,), dtype=torch.float64, **kw)
+
+
+def engine_arm(tag):
+    """The same kernels through uav_ac.fleet.Engine (what bench.py and tools/sampler_time.py do), its own buffers."""
+    from uav_ac.fleet import Engine
+    global _eng, _plan
+    if "_eng" not in globals():
+        _eng = Engine("cuda:0")
+        _plan = _eng.plan(missions(B, M, 0, B), 3.0, 0.01)
+    y = _plan.yaw
+    t_sy = timed(lambda: _eng.sample(_plan), reps=10)
+    _plan.yaw = None
+    t_s = timed(lambda: _eng.sample(_plan), reps=10)
+    _plan.yaw = y
+    # and the raw entry point of the in-tree library on the Engine's buffers
+    lib, h = libs["new"]
+    q = _plan
+    t_raw = timed(lambda: lib.uavac_minsnap_sample_yaw_dev(h, p(q.coeffs), p(q.times), p(q.seg_rows), p(q.row_offsets), B, M, 0.01,
+                                                            p(q.traj), p(q.yaw)), reps=10)
+    print(json.dumps({"engine_arm": tag, "sample_ms": round(t_s, 4), "sample_yaw_ms": round(t_sy, 4),
+                      "raw_call_on_engine_buffers_ms": round(t_raw, 4), "traj_addr": hex(q.traj.data_ptr()),
+                      "yaw_addr": hex(q.yaw.data_ptr())}), flush=True)
+
+
+print(json.dumps({"raw_buffers": {"traj": hex(traj.data_ptr()), "yaw": hex(yaw.data_ptr())}}))
+engine_arm("before")
+for rnd in range(3):
+    for name, (lib, h) in libs.items():
+        t_counts = timed(lambda: lib.uavac_minsnap_row_counts_dev(h, p(wp), B, M, 3.0, 0.01, p(times), p(seg), p(ro)))
+        t_solve = timed(lambda: lib.uavac_minsnap_solve_dev(h, p(wp), p(times), B, M, p(co), p(st)))
+        t_s = timed(lambda: lib.uavac_minsnap_sample_dev(h, p(co), p(times), p(seg), p(ro), B, M, 0.01, p(traj)))
+        t_sy = timed(lambda: lib.uavac_minsnap_sample_yaw_dev(h, p(co), p(times), p(seg), p(ro), B, M, 0.01, p(traj), p(yaw)))
+        print(json.dumps({"round": rnd, "lib": name, "row_counts_ms": round(t_counts, 4), "solve_ms": round(t_solve, 4),
+                          "sample_ms": round(t_s, 4), "sample_yaw_ms": round(t_sy, 4),
+                          "sample_yaw_TBps": round((N * 96) / t_sy / 1e9, 3)}), flush=True)
+engine_arm("after")
+# allocation dependence: new buffers each time (the caching allocator is emptied in between)
+lib, h = libs["new"]
+keep = []
+for i in range(6):
+    del traj, yaw
+    if i % 2 == 0:
+        torch.cuda.empty_cache()
+    if i >= 3:
+        keep.append(torch.empty(((i * 37 + 11) << 20,), dtype=torch.uint8, device=dev))   # shift the next block's address
+    traj = torch.empty((N, 11), dtype=torch.float64, **kw)
+    yaw = torch.empty((N,), dtype=torch.float64, **kw)
+    t_sy = timed(lambda: lib.uavac_minsnap_sample_yaw_dev(h, p(co), p(times), p(seg), p(ro), B, M, 0.01, p(traj), p(yaw)))
+    print(json.dumps({"fresh_alloc": i, "traj_addr_mod_2MiB": traj.data_ptr() % (2 << 20), "sample_yaw_ms": round(t_sy, 4)}), flush=True)

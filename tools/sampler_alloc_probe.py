@@ -1,0 +1,40 @@
+"""Why does the sampler take 1.40 ms on some runs and 1.75 ms on others?  Individually timed passes over (1) the first
+row buffer a process allocates, (2) freshly allocated ones, (3) the first one again, (4) any of them with 7 GB of other
+writes between passes (what the bench does: the log stream runs between two planning stages)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
+import numpy as np, torch
+from bench import missions
+from uav_ac.fleet import Engine
+B, M = 65536, 12
+eng = Engine("cuda:0")
+plan = eng.plan(missions(B, M, 0, B), 3.0, 0.01)
+N = plan.total_rows
+def passes(n, between=None):
+    out = []
+    for _ in range(n):
+        if between is not None: between()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); eng.sample(plan); b.record(); torch.cuda.synchronize()
+        out.append(round(a.elapsed_time(b), 3))
+    return out
+print(json.dumps({"first_alloc_40_passes": passes(40)}), flush=True)
+first = (plan.traj, plan.yaw)
+plan.traj = torch.empty_like(first[0]); plan.yaw = torch.empty_like(first[1])
+print(json.dumps({"second_alloc_40_passes": passes(40), "addr": hex(plan.traj.data_ptr())}), flush=True)
+second = (plan.traj, plan.yaw)
+plan.traj, plan.yaw = first
+print(json.dumps({"first_alloc_again_10": passes(10)}), flush=True)
+other = torch.empty((7 << 30,), dtype=torch.uint8, device="cuda:0")
+print(json.dumps({"first_alloc_with_7GB_fill_between": passes(12, lambda: other.fill_(1))}), flush=True)
+plan.traj, plan.yaw = second
+print(json.dumps({"second_alloc_with_7GB_fill_between": passes(12, lambda: other.fill_(1))}), flush=True)
+print(json.dumps({"second_alloc_again_10": passes(10)}), flush=True)
+fleet = eng.fleet(plan)
+log = torch.empty((1000, 13, B), dtype=torch.float64, device="cuda:0")
+def roll():
+    fleet.reset()
+    for _ in range(3): fleet.rollout(1000, state_log=log)
+print(json.dumps({"second_alloc_with_3_rollouts_between": passes(12, roll)}), flush=True)
+print(torch.cuda.memory_summary(abbreviated=True)[:600])

@@ -143,7 +143,7 @@ struct Scratch {
 template <class Kern>
 int run_probe(uavac_ctx *ctx, const uavac_vehicle *V, Kern kern, const double *in, int nin, int B, int mask,
               double *out, int nout) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (B < 1 || !in || !out) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
     Scratch din, dout;
@@ -172,7 +172,7 @@ int uavac_probe_inner(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, 
 
 int uavac_controller_tick_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,
                               double *state, int32_t *istate, int B) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (B < 1 || !traj || !row_offsets || !state || !istate) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
     hipLaunchKernelGGL(controller_tick_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, uavac_make_vehk(*V), traj,
@@ -183,7 +183,7 @@ int uavac_controller_tick_dev(uavac_ctx *ctx, const uavac_vehicle *V, const doub
 
 int uavac_dynamics_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate, int B,
                             const double *aabbs, int n_obs) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (B < 1 || !state || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
     hipLaunchKernelGGL(dynamics_step_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, uavac_make_vehk(*V), state,
@@ -194,7 +194,7 @@ int uavac_dynamics_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, double *stat
 
 int uavac_controller_tick(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,
                           double *state, int32_t *istate, int B) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (B < 1 || !traj || !row_offsets || !state || !istate) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
     if (row_offsets[0] != 0) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must start at 0");
     const size_t total = (size_t)row_offsets[B];
@@ -217,7 +217,7 @@ int uavac_controller_tick(uavac_ctx *ctx, const uavac_vehicle *V, const double *
 
 int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate, int B,
                         const double *aabbs, int n_obs) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (B < 1 || !state || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
     Scratch ds, di, dab;
     UAVAC_HIP(ctx, hipMalloc(&ds.p, (size_t)B * UAVAC_STATE_ROWS * 8));

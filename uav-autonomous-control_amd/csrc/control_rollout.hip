@@ -30,6 +30,7 @@
 #include "minsnap_eval.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -94,8 +95,8 @@ __device__ __forceinline__ VehK outer_constants() {
 // drops from 1.3 GB to 0.1 GB at B = 65 536.  Coefficients [24][64] and yaws [16][64] of a compute wave live in LDS.
 constexpr int kPolyTileDoubles = (24 + 16) * 64;
 
-template <int CW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY>
-__global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD) ? 64 : 0))
+template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY>
+__global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD) ? 64 * SW : 0))
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
                        double *__restrict__ state_log, double *__restrict__ cmd_log,
@@ -112,15 +113,18 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     const int col0 = col_base + xcd_contiguous(blockIdx.x, gridDim.x) * NU;     // the launch covers [col_base, col_base + grid NU)
 
     if (LOGGING && threadIdx.x >= NU) {
-        // ------------------------------------------------------------------------------ store wave
-        const int lane = threadIdx.x - NU;
+        // ------------------------------------------------------------------------------ store wave(s)
+        // SW store waves share the workgroup's NU columns: store wave w covers columns [w, w + 1) * QPL * 64, QPL
+        // 64-column blocks of it per lane.
+        constexpr int QPL = CW / SW;
+        const int lane = (threadIdx.x & 63) + ((threadIdx.x - NU) >> 6) * (QPL * 64);
         __builtin_amdgcn_s_setprio(3);            // few instructions, all on the critical store stream: issue first
         const bool full = col0 + NU <= B;          // every column of this workgroup exists: no per-store mask
         // With a state log the per-tick obstacle test runs HERE, on the positions this wave is about to store, after
         // its stores have been issued: the compute wave's tick stays as short as without obstacles (the two stages
         // couple through one barrier per tick; lengthening the compute stage to the length of the store stage cost
         // 40 % at config 5), and the comparisons fill time in which this wave would wait for the store path anyway.
-        constexpr bool AABB_HERE = AABB && LOG_STATE && CW == 1;
+        constexpr bool AABB_HERE = AABB && LOG_STATE && QPL == 1;
         const bool mine = col0 + lane < B;
         int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
         for (int k = 0; k < K; ++k) {
@@ -129,16 +133,16 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             // one log (13 or 12 rows) at a time: every LDS read first, then every store, so that neither the
             // LDS latency nor the store path's acceptance time is paid per element
             if (LOG_STATE) {
-                double v[13][CW];
+                double v[13][QPL];
 #pragma unroll
                 for (int r = 0; r < 13; ++r)
 #pragma unroll
-                    for (int q = 0; q < CW; ++q) v[r][q] = src[r * NU + q * 64];
+                    for (int q = 0; q < QPL; ++q) v[r][q] = src[r * NU + q * 64];
                 double *dst = state_log + (size_t)k * 13 * sB + col0 + lane;
 #pragma unroll
                 for (int r = 0; r < 13; ++r)
 #pragma unroll
-                    for (int q = 0; q < CW; ++q)
+                    for (int q = 0; q < QPL; ++q)
                         if (full || col0 + q * 64 + lane < B) dst[r * sB + q * 64] = v[r][q];      // 512-B coalesced wave store
                 if (AABB_HERE) {
                     const double x = v[0][0], y = v[1][0], z = v[2][0];
@@ -151,16 +155,16 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 }
             }
             if (LOG_CMD) {
-                double v[UAVAC_CMD_COLS][CW];
+                double v[UAVAC_CMD_COLS][QPL];
 #pragma unroll
                 for (int r = 0; r < UAVAC_CMD_COLS; ++r)
 #pragma unroll
-                    for (int q = 0; q < CW; ++q) v[r][q] = src[(CMD0 + r) * NU + q * 64];
+                    for (int q = 0; q < QPL; ++q) v[r][q] = src[(CMD0 + r) * NU + q * 64];
                 double *dst = cmd_log + (size_t)k * UAVAC_CMD_COLS * sB + col0 + lane;
 #pragma unroll
                 for (int r = 0; r < UAVAC_CMD_COLS; ++r)
 #pragma unroll
-                    for (int q = 0; q < CW; ++q)
+                    for (int q = 0; q < QPL; ++q)
                         if (full || col0 + q * 64 + lane < B) dst[r * sB + q * 64] = v[r][q];
             }
         }
@@ -296,7 +300,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         free_body_step(V, om, px, py, pz, q0, q1, q2, q3, vx, vy, vz, wp, wq, wr, inv_n2);
         inv_n2 = 1.0;
 
-        if (AABB && !(LOG_STATE && CW == 1)) {             // with a state log the store wave tests the logged positions
+        if (AABB && !(LOG_STATE && CW == SW)) {            // with a state log the store wave tests the logged positions
             for (int o = 0; o < n_obs; ++o) {
                 const double *c = aabbs + 6 * o;          // uniform address: scalar loads
                 const bool hit = (px >= c[0]) && (px <= c[1]) && (py >= c[2]) && (py <= c[3]) && (pz >= c[4]) &&
@@ -330,7 +334,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     state[23 * sB + b] = pc; state[24 * sB + b] = qc; state[25 * sB + b] = rc;
     istate[0 * sB + b] = idx;
     istate[1 * sB + b] = inner;
-    if (!(AABB && LOG_STATE && CW == 1)) istate[2 * sB + b] = collided;
+    if (!(AABB && LOG_STATE && CW == SW)) istate[2 * sB + b] = collided;
 }
 
 __global__ void state_init_kernel(const VehK V, const double *__restrict__ positions, int B, int hover,
@@ -351,49 +355,79 @@ __global__ void state_init_kernel(const VehK V, const double *__restrict__ posit
     for (int r = 0; r < UAVAC_ISTATE_ROWS; ++r) istate[r * sB + b] = 0;
 }
 
-constexpr int kColumnsPerLaunch = 256 * 4 * 64;          // one 64-UAV workgroup per SIMD of the chip
+constexpr int kColumnsPerLaunch = 256 * 4 * 64;          // one 64-UAV compute wave per SIMD of the chip
 
-template <int CW, bool LS, bool LC, bool AB, bool POLY>
+// Empty kernel with the workgroup shape of the logged rollout (two waves).  Where the dispatcher puts the waves of a
+// 2-wave workgroup depends on the shape of the kernel that ran before: after the planning kernels (1-wave
+// workgroups) 5-15 % of the SIMDs receive two compute waves and others two store waves, and the launch runs 25 %
+// slower (tools/first_launch_bisect.py, tools/placement_after_sampler.py; it heals by itself over the next two
+// launches).  After ANY kernel of 2-wave workgroups the placement is one compute + one store wave on every SIMD.
+__global__ void __launch_bounds__(128) rollout_align_kernel() {}
+
+// Workgroup shape of a logged launch (ctx->rollout_shape, uavac_set_option "rollout_shape"): 1 = one compute + one
+// store wave per 64 UAVs, preceded by the aligner (ctx->rollout_align); 4 = four compute + four store waves per 256
+// UAVs (one workgroup per CU: the dispatcher deals the 8 waves of a workgroup round the 4 SIMDs, so every SIMD gets one
+// of each whatever ran before), used for full-chip launches of 65 536 columns.
+template <int CW, int SW, bool LS, bool LC, bool AB, bool POLY>
+void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
+                  int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
+                  const PlanRef &P, int base, int cols) {
+    constexpr int NU = 64 * CW;
+    constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0);
+    constexpr int threads = NU + ((LS || LC) ? 64 * SW : 0);
+    const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * kPolyTileDoubles : 0));
+    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((cols + NU - 1) / NU), dim3(threads), lds, ctx->stream, V, traj, row_offsets, state,
+                       istate, B, K, state_log, cmd_log, aabbs, n_obs, base, P);
+    auto tf = [](bool v) { return v ? "true" : "false"; };
+    char name[160];
+    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY));
+    ctx->last_rollout = name;
+}
+
+template <bool LS, bool LC, bool AB, bool POLY>
 void launch_poly(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                  int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                  const PlanRef &P) {
-    constexpr int NU = 64 * CW;
-    constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0);
-    constexpr int threads = NU + ((LS || LC) ? 64 : 0);
-    const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * kPolyTileDoubles : 0));
-    auto kern = control_rollout_kernel<CW, LS, LC, AB, POLY>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    // With logs, batches beyond one workgroup per SIMD go out as consecutive launches of kColumnsPerLaunch UAVs:
+    constexpr bool LOGGING = LS || LC;
+    // With logs, batches beyond one compute wave per SIMD go out as consecutive launches of kColumnsPerLaunch UAVs:
     // measured per 1 000 ticks, B = 131 072 in one launch 4.04 ms, as 2 x 65 536 3.3 ms (two workgroups per SIMD
     // make the compute and store waves of a CU queue on each other).  Results do not depend on the split.
-    const int per_launch = (LS || LC) ? kColumnsPerLaunch : B;
+    const int per_launch = LOGGING ? kColumnsPerLaunch : B;
     for (int base = 0; base < B; base += per_launch) {
         const int cols = (B - base < per_launch) ? B - base : per_launch;
-        hipLaunchKernelGGL(kern, dim3((cols + NU - 1) / NU), dim3(threads), lds, ctx->stream, V, traj, row_offsets, state,
-                           istate, B, K, state_log, cmd_log, aabbs, n_obs, base, P);
+#define UAVAC_SHAPE_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, P, base, cols
+        if (LOGGING && ctx->rollout_shape == 4 && cols == kColumnsPerLaunch) {
+            launch_shape<4, 4, LS, LC, AB, POLY>(UAVAC_SHAPE_ARGS);
+        } else {
+            if (LOGGING && ctx->rollout_align)
+                hipLaunchKernelGGL(rollout_align_kernel, dim3((cols + 63) / 64), dim3(128), 0, ctx->stream);
+            launch_shape<1, 1, LS, LC, AB, POLY>(UAVAC_SHAPE_ARGS);
+        }
+#undef UAVAC_SHAPE_ARGS
     }
 }
 
-template <int CW, bool LS, bool LC, bool AB>
+template <bool LS, bool LC, bool AB>
 void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                     int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                     const PlanRef *plan) {
-    if (plan) launch_poly<CW, LS, LC, AB, true>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, *plan);
-    else launch_poly<CW, LS, LC, AB, false>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, PlanRef{});
+    if (plan) launch_poly<LS, LC, AB, true>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, *plan);
+    else launch_poly<LS, LC, AB, false>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, PlanRef{});
 }
 
-template <int CW>
-void launch_cw(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
-               int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
-               const PlanRef *plan) {
+void launch_flags(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
+                  int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
+                  const PlanRef *plan) {
     const bool ls = state_log != nullptr, lc = cmd_log != nullptr, ab = (aabbs != nullptr && n_obs > 0);
 #define UAVAC_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, plan
     if (ls) {
-        if (lc) { if (ab) launch_variant<CW, true, true, true>(UAVAC_ARGS); else launch_variant<CW, true, true, false>(UAVAC_ARGS); }
-        else    { if (ab) launch_variant<CW, true, false, true>(UAVAC_ARGS); else launch_variant<CW, true, false, false>(UAVAC_ARGS); }
+        if (lc) { if (ab) launch_variant<true, true, true>(UAVAC_ARGS); else launch_variant<true, true, false>(UAVAC_ARGS); }
+        else    { if (ab) launch_variant<true, false, true>(UAVAC_ARGS); else launch_variant<true, false, false>(UAVAC_ARGS); }
     } else {
-        if (lc) { if (ab) launch_variant<CW, false, true, true>(UAVAC_ARGS); else launch_variant<CW, false, true, false>(UAVAC_ARGS); }
-        else    { if (ab) launch_variant<CW, false, false, true>(UAVAC_ARGS); else launch_variant<CW, false, false, false>(UAVAC_ARGS); }
+        if (lc) { if (ab) launch_variant<false, true, true>(UAVAC_ARGS); else launch_variant<false, true, false>(UAVAC_ARGS); }
+        else    { if (ab) launch_variant<false, false, true>(UAVAC_ARGS); else launch_variant<false, false, false>(UAVAC_ARGS); }
     }
 #undef UAVAC_ARGS
 }
@@ -419,7 +453,7 @@ int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, cons
     // LDS, so that the compute wave may run 4 ticks ahead of a stalled store wave, was slower as well: 1.35 vs
     // 1.26 ms -- the hand-over is not what limits the kernel.)  The log rows want B to be a multiple of 16 (128-B lines): B = 65 534 runs at half
     // the rate of B = 65 536 because every 512-B wave store then straddles two partially written lines.
-    launch_cw<1>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, plan);
+    launch_flags(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, plan);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

@@ -20,3 +20,23 @@ __device__ __forceinline__ void minsnap_eval_row(const double *c, double t, doub
     vx = d1x; vy = d1y; vz = d1z;
     ax = 2.0 * d2x; ay = 2.0 * d2y; az = 2.0 * d2z;
 }
+
+// Third and fourth derivative of the same polynomials (polynom(8, 3, t) @ coeffs and polynom(8, 4, t) @ coeffs,
+// minimum_snap.py:111-112): Horner with running derivatives carried two levels further, d_k = p^(k) / k!.
+template <int STRIDE>
+__device__ __forceinline__ void minsnap_eval_jerk_snap(const double *c, double t, double jerk[3], double snap[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double p = c[(21 + a) * STRIDE], d1 = 0, d2 = 0, d3 = 0, d4 = 0;
+#pragma unroll
+        for (int i = 6; i >= 0; --i) {
+            d4 = fma(d4, t, d3);
+            d3 = fma(d3, t, d2);
+            d2 = fma(d2, t, d1);
+            d1 = fma(d1, t, p);
+            p = fma(p, t, c[(3 * i + a) * STRIDE]);
+        }
+        jerk[a] = 6.0 * d3;
+        snap[a] = 24.0 * d4;
+    }
+}

@@ -50,13 +50,66 @@ __device__ __forceinline__ int segment_of(const int *__restrict__ pre, int m, in
     return s;
 }
 
-template <bool HITS>
+// |v_xy| >= MIN_HORIZONTAL_SPEED_FOR_YAW as NumPy evaluates it (np.linalg.norm(..., axis=1) = sqrt(add.reduce(x * x)):
+// two rounded products, one rounded sum -- no fused multiply-add)
+__device__ __forceinline__ bool has_heading(double vx, double vy) {
+    return sqrt(__dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy))) >= kMinSpeedForYaw;
+}
+
+// State of _calculate_yaws carried from one 64-row chunk to the next (wave-uniform): has a usable heading been seen,
+// its raw angle, and the running sum of np.unwrap's corrections.
+struct YawCarry {
+    bool has = false;
+    double ang = 0.0, sum = 0.0;
+};
+
+// One chunk of the yaw scan (minimum_snap.py:126-136): lane i holds row c0 + i (valid: its heading `ang` is usable).
+// Returns the row's yaw: the unwrapped heading of the last usable row at or before it; rows before the sequence's first
+// usable heading get that heading when it lies in this chunk (first_here / first_yaw; whole chunks of such rows that
+// came earlier hold the placeholder 0 and are patched by the caller) and 0 otherwise.
+__device__ __forceinline__ double yaw_chunk(bool valid, double ang, int lane, YawCarry &carry, bool &first_here,
+                                            double &first_yaw) {
+    // last valid heading strictly before this row: inside the chunk via ballot, else the carry
+    const unsigned long long mask = __ballot(valid);
+    const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+    bool prev_has = lower != 0ull;
+    double prev_ang = __shfl(ang, prev_has ? 63 - __clzll((long long)lower) : 0);
+    if (!prev_has && carry.has) { prev_has = true; prev_ang = carry.ang; }
+    const double corr = (valid && prev_has) ? unwrap_correction(ang - prev_ang) : 0.0;
+    double incl = corr;                       // inclusive prefix sum of the corrections in this chunk
+    if (__ballot(corr != 0.0) != 0ull) {      // headings rarely wrap: most chunks skip the scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+    }
+    const double cum = carry.sum + incl;
+    // rows before the mission's first valid heading take that heading (np.searchsorted(...)-1 clipped to 0)
+    first_here = !carry.has && mask != 0ull;
+    const int first_lane = first_here ? __builtin_ctzll(mask) : 0;
+    first_yaw = lane_value(ang, first_lane);       // its unwrap sum is 0 by construction
+    double yaw;
+    if (valid || prev_has) yaw = (valid ? ang : prev_ang) + cum;
+    else yaw = first_here ? first_yaw : 0.0;                   // 0 = placeholder, patched by the caller if needed
+    carry.sum += lane_value(incl, 63);
+    if (mask != 0ull) { carry.has = true; carry.ang = lane_value(ang, 63 - __clzll((long long)mask)); }
+    return yaw;
+}
+
+// HITS: also flag the splines whose samples enter the cuboid aabb (collision scan of the obstacle re-plan loop).
+// DERIVS: also write jerk / snap, [N][3] each -- the two outputs the reference computes in comments only
+// (minimum_snap.py:111-112,118-119: polynom(8, 3 | 4, t) @ coeffs); separate arrays, never extra row columns.
+// capacity_rows >= 0: the row buffer holds that many rows; a plan that needs more is refused as a whole (flag 2).
+template <bool HITS, bool DERIVS>
 __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__restrict__ coeffs,
                                                            const int32_t *__restrict__ seg_rows,
                                                            const int64_t *__restrict__ row_offsets, int B, int m,
                                                            double dt, double *__restrict__ traj,
                                                            const double *__restrict__ aabb, int32_t *__restrict__ hit,
-                                                           double *__restrict__ yaw_dense) {
+                                                           double *__restrict__ yaw_dense, double *__restrict__ jerk,
+                                                           double *__restrict__ snap, int64_t capacity_rows,
+                                                           int32_t *__restrict__ flags) {
     extern __shared__ double lds[];
     double *stage = lds;                         // [SB*11]
     double *cl = stage + SB * UAVAC_TRAJ_COLS;   // [24*m] coefficients of this mission
@@ -69,6 +122,10 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     const int b = xcd_contiguous(blockIdx.x, gridDim.x);      // consecutive missions (consecutive rows in HBM) per XCD
     const int64_t row0 = row_offsets[b];
     const int N = (int)(row_offsets[b + 1] - row0);
+    if (capacity_rows >= 0 && row_offsets[B] > capacity_rows) {       // uniform over the launch: nobody writes
+        if (blockIdx.x == 0 && lane == 0) atomicOr(&flags[2], 1);
+        return;
+    }
 
     for (int i = lane; i < 24 * m; i += SB) cl[i] = coeffs[(size_t)b * 24 * m + i];
     {   // exclusive prefix of the per-segment row counts: lane s holds segment s (m <= 64)
@@ -86,8 +143,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
 
     // carried across chunks (wave-uniform): has a valid heading been seen, its raw angle, the running
     // unwrap sum (np.cumsum of np.unwrap's corrections), and the heading used for the back-fill
-    bool carry_has = false;
-    double carry_ang = 0.0, carry_sum = 0.0;
+    YawCarry carry;
     int s = 0;
     for (int c0 = 0; c0 < N; c0 += SB) {
         const int r = c0 + lane;
@@ -98,6 +154,13 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             const double t = (double)(r - pre[s]) * dt;
             const double *c = cl + s * 24;
             minsnap_eval_row<1>(c, t, px, py, pz, vx, vy, vz, ax, ay, az);
+            if (DERIVS) {
+                double j[3], q[3];
+                minsnap_eval_jerk_snap<1>(c, t, j, q);
+                const size_t o = (size_t)(row0 + r) * 3;
+                if (jerk) { jerk[o] = j[0]; jerk[o + 1] = j[1]; jerk[o + 2] = j[2]; }
+                if (snap) { snap[o] = q[0]; snap[o + 1] = q[1]; snap[o + 2] = q[2]; }
+            }
         }
         if (HITS) {
             // inclusive AABB test on the sampled position (minimum_snap.py:327-357); flags the row's spline
@@ -105,32 +168,11 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                             pz >= aabb[4] && pz <= aabb[5];
             if (in) atomicOr(&hit[(size_t)b * m + s], 1);
         }
-        const bool valid = active && (sqrt(vx * vx + vy * vy) >= kMinSpeedForYaw);
+        const bool valid = active && has_heading(vx, vy);
         const double ang = valid ? atan2(vy, vx) : 0.0;
-
-        // last valid heading strictly before this row: inside the chunk via ballot, else the carry
-        const unsigned long long mask = __ballot(valid);
-        const unsigned long long lower = mask & ((1ull << lane) - 1ull);
-        bool prev_has = lower != 0ull;
-        double prev_ang = __shfl(ang, prev_has ? 63 - __clzll((long long)lower) : 0);
-        if (!prev_has && carry_has) { prev_has = true; prev_ang = carry_ang; }
-        const double corr = (valid && prev_has) ? unwrap_correction(ang - prev_ang) : 0.0;
-        double incl = corr;                       // inclusive prefix sum of the corrections in this chunk
-        if (__ballot(corr != 0.0) != 0ull) {      // headings rarely wrap: most chunks skip the scan
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-        }
-        const double cum = carry_sum + incl;
-        // rows before the mission's first valid heading take that heading (np.searchsorted(...)-1 clipped to 0)
-        const bool first_here = !carry_has && mask != 0ull;
-        const int first_lane = first_here ? __builtin_ctzll(mask) : 0;
-        const double first_yaw = lane_value(ang, first_lane);       // its unwrap sum is 0 by construction
-        double yaw;
-        if (valid || prev_has) yaw = (valid ? ang : prev_ang) + cum;
-        else yaw = first_here ? first_yaw : 0.0;                   // 0 = placeholder, patched below if needed
+        bool first_here;
+        double first_yaw;
+        const double yaw = yaw_chunk(valid, ang, lane, carry, first_here, first_yaw);
         if (first_here && c0 > 0) {
             // the first usable heading arrived after whole chunks of placeholders: patch their yaw column
             // (same wave, same addresses, program order => the later store wins)
@@ -142,10 +184,6 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                 for (int i = flushed + lane; i < c0; i += SB) ybuf[i - flushed] = first_yaw;
             }
         }
-        // carries (wave-uniform)
-        carry_sum += lane_value(incl, 63);
-        if (mask != 0ull) { carry_has = true; carry_ang = lane_value(ang, 63 - __clzll((long long)mask)); }
-
         if (yaw_dense) {
             const int g0 = (c0 / (kYawGroup * SB)) * (kYawGroup * SB);          // first row of this group of chunks
             if (active) ybuf[r - g0] = yaw;
@@ -181,20 +219,51 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     }
 }
 
+// _calculate_yaws (minimum_snap.py:126-136) on its own: B independent velocity sequences, sequence b = rows
+// [offsets[b], offsets[b+1]) of velocities[.][3]; one wavefront per sequence, 64 rows per step.
+__global__ void __launch_bounds__(SB) yaw_scan_kernel(const double *__restrict__ vel, const int64_t *__restrict__ offsets,
+                                                     double *__restrict__ yaws) {
+    const int lane = threadIdx.x;
+    const int64_t row0 = offsets[blockIdx.x];
+    const int64_t N = offsets[blockIdx.x + 1] - row0;
+    YawCarry carry;
+    for (int64_t c0 = 0; c0 < N; c0 += SB) {
+        const int64_t r = c0 + lane;
+        const bool active = r < N;
+        const double vx = active ? vel[(row0 + r) * 3] : 0.0, vy = active ? vel[(row0 + r) * 3 + 1] : 0.0;
+        const bool valid = active && has_heading(vx, vy);
+        const double ang = valid ? atan2(vy, vx) : 0.0;
+        bool first_here;
+        double first_yaw;
+        const double yaw = yaw_chunk(valid, ang, lane, carry, first_here, first_yaw);
+        if (first_here && c0 > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the placeholders are down before they are replaced
+            for (int64_t i = lane; i < c0; i += SB) yaws[row0 + i] = first_yaw;
+        }
+        if (active) yaws[row0 + r] = yaw;
+    }
+}
+
 }  // namespace
 
+int uavac_launch_yaw_scan(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B, double *yaws) {
+    hipLaunchKernelGGL(yaw_scan_kernel, dim3(B), dim3(SB), 0, ctx->stream, velocities, offsets, yaws);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
-                        int B, int m, double dt, double *traj, const double *aabb, int32_t *hit, double *yaw_dense) {
+                        int B, int m, double dt, double *traj, const SampleExtras &x) {
     size_t lds = sizeof(double) * ((size_t)SB * UAVAC_TRAJ_COLS + (size_t)24 * m) + sizeof(int) * (size_t)((m + 2 + 1) & ~1) +
-                 (yaw_dense ? sizeof(double) * kYawGroup * SB : 0);
-    if (aabb && hit) {
-        UAVAC_HIP(ctx, hipMemsetAsync(hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
-        hipLaunchKernelGGL(minsnap_sample_kernel<true>, dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows,
-                           row_offsets, B, m, dt, traj, aabb, hit, yaw_dense);
-    } else {
-        hipLaunchKernelGGL(minsnap_sample_kernel<false>, dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows,
-                           row_offsets, B, m, dt, traj, aabb, hit, yaw_dense);
-    }
+                 (x.yaw_dense ? sizeof(double) * kYawGroup * SB : 0);
+    const bool hits = x.aabb && x.hit, derivs = x.jerk || x.snap;
+    if (hits) UAVAC_HIP(ctx, hipMemsetAsync(x.hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
+#define UAVAC_SAMPLE(H, D)                                                                                             \
+    hipLaunchKernelGGL((minsnap_sample_kernel<H, D>), dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows, row_offsets, \
+                       B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags)
+    if (hits) { if (derivs) UAVAC_SAMPLE(true, true); else UAVAC_SAMPLE(true, false); }
+    else      { if (derivs) UAVAC_SAMPLE(false, true); else UAVAC_SAMPLE(false, false); }
+#undef UAVAC_SAMPLE
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

@@ -54,37 +54,12 @@ __constant__ double kW[32] = {
     20, 10, 2, 1.0 / 6.0, -20, 10, -2, 1.0 / 6.0};
 
 // ------------------------------------------------------------------------------------------
-// Times and row counts: one thread per mission.  No FMA contraction here so that T (and with it
-// ceil(T/dt)) is the plain IEEE sequence sqrt(dx*dx + dy*dy + dz*dz) / v [* 1.5].
-__global__ void row_counts_kernel(const double *__restrict__ wp, int B, int m, double velocity, double dt,
-                                  double *__restrict__ times, int32_t *__restrict__ seg_rows,
-                                  int32_t *__restrict__ totals, int32_t *__restrict__ flags) {
-#pragma clang fp contract(off)
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double *w = wp + (size_t)b * (m + 1) * 3;
-    double x0 = w[0], y0 = w[1], z0 = w[2];
-    int total = 0;
-    bool bad = !(isfinite(x0) && isfinite(y0) && isfinite(z0));
-    for (int s = 0; s < m; ++s) {
-        double x1 = w[3 * s + 3], y1 = w[3 * s + 4], z1 = w[3 * s + 5];
-        double dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
-        double T = sqrt(dx * dx + dy * dy + dz * dz) / velocity;
-        if (s == 0 || s == m - 1) T = T * 1.5;      // START_END_TIME_FACTOR, minimum_snap.py:10,318-320
-        bad = bad || !isfinite(T);
-        double q = ceil(T / dt);
-        int rows = (isfinite(q) && q > 0.0 && q < 2.0e9) ? (int)q : 0;
-        times[(size_t)b * m + s] = T;
-        seg_rows[(size_t)b * m + s] = rows;
-        total += rows;
-        x0 = x1; y0 = y1; z0 = z1;
-    }
-    totals[b] = total;
-    if (bad) atomicOr(&flags[0], 1);
-}
-
-// Exclusive prefix sum of totals[B] -> row_offsets[B+1] (int64), two levels, every access coalesced:
-// (1) per-256 tile sums, (2) one workgroup scans the tile sums, (3) each tile scans itself on top of its base.
+// Times and row counts: one thread per mission, 256 missions per workgroup, which also leaves the tile's row total.
+// T = np.linalg.norm(wp[i+1] - wp[i]) / velocity [* 1.5] (minimum_snap.py:315-320).  For a 3-vector NumPy's norm is
+// sqrt(x.dot(x)) and BLAS ddot accumulates with fused multiply-adds: sqrt(fma(dz, dz, fma(dy, dy, dx * dx))) -- the
+// committed reference times are reproduced bit for bit by this form only (the plain sum of squares differs in the
+// last bit for ~8 % of the segments, which moves ceil(T/dt) by one row whenever T/dt sits on an integer).  No other
+// contraction: the division, the factor and ceil(T/dt) are the plain IEEE sequence of len(np.arange(0, T, dt)).
 __device__ __forceinline__ int64_t block_inclusive_scan_256(int64_t v, int64_t *wsum /* [4] shared */) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -99,35 +74,57 @@ __device__ __forceinline__ int64_t block_inclusive_scan_256(int64_t v, int64_t *
     return v + base;
 }
 
-__global__ void __launch_bounds__(256) tile_sums_kernel(const int32_t *__restrict__ totals, int B,
-                                                        int64_t *__restrict__ tile_sum) {
+__global__ void __launch_bounds__(256) row_counts_kernel(const double *__restrict__ wp, int B, int m, double velocity,
+                                                         double dt, double *__restrict__ times,
+                                                         int32_t *__restrict__ seg_rows, int32_t *__restrict__ totals,
+                                                         int64_t *__restrict__ tile_sum, int32_t *__restrict__ flags) {
+#pragma clang fp contract(off)
     __shared__ int64_t wsum[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int64_t inc = block_inclusive_scan_256(i < B ? totals[i] : 0, wsum);
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = 0;
+    if (b < B) {
+        const double *w = wp + (size_t)b * (m + 1) * 3;
+        double x0 = w[0], y0 = w[1], z0 = w[2];
+        bool bad = !(isfinite(x0) && isfinite(y0) && isfinite(z0));
+        for (int s = 0; s < m; ++s) {
+            double x1 = w[3 * s + 3], y1 = w[3 * s + 4], z1 = w[3 * s + 5];
+            double dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
+            double T = sqrt(fma(dz, dz, fma(dy, dy, dx * dx))) / velocity;
+            if (s == 0 || s == m - 1) T = T * 1.5;      // START_END_TIME_FACTOR, minimum_snap.py:10,318-320
+            bad = bad || !isfinite(T);
+            double q = ceil(T / dt);
+            int rows = (isfinite(q) && q > 0.0 && q < 2.0e9) ? (int)q : 0;
+            times[(size_t)b * m + s] = T;
+            seg_rows[(size_t)b * m + s] = rows;
+            total += rows;
+            x0 = x1; y0 = y1; z0 = z1;
+        }
+        if (total > 2147483647LL) { atomicOr(&flags[3], 1); total = 0; }     // a mission's rows are indexed with int
+        totals[b] = (int32_t)total;
+        if (bad) atomicOr(&flags[0], 1);
+    }
+    const int64_t inc = block_inclusive_scan_256(total, wsum);
     if (threadIdx.x == 255) tile_sum[blockIdx.x] = inc;
 }
 
-__global__ void __launch_bounds__(256) scan_tiles_kernel(int64_t *__restrict__ tile_sum, int n_tiles) {
+// Exclusive prefix sum of totals[B] -> row_offsets[B+1] (int64): every workgroup adds up the sums of the tiles before
+// its own (B / 256 values at most: 256 at B = 65 536) and scans its tile on top of that.  Two launches in all, every
+// access coalesced, no inter-workgroup waiting.
+__global__ void __launch_bounds__(256) row_offsets_kernel(const int32_t *__restrict__ totals, int B,
+                                                          const int64_t *__restrict__ tile_sum,
+                                                          int64_t *__restrict__ row_offsets) {
     __shared__ int64_t wsum[4];
-    int64_t carry = 0;
-    for (int t0 = 0; t0 < n_tiles; t0 += 256) {
-        const int i = t0 + threadIdx.x;
-        const int64_t v = i < n_tiles ? tile_sum[i] : 0;
-        const int64_t inc = block_inclusive_scan_256(v, wsum);
-        if (i < n_tiles) tile_sum[i] = carry + inc - v;          // exclusive base of tile i
-        __syncthreads();
-        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
-    }
-}
-
-__global__ void __launch_bounds__(256) tile_offsets_kernel(const int32_t *__restrict__ totals, int B,
-                                                           const int64_t *__restrict__ tile_base,
-                                                           int64_t *__restrict__ row_offsets) {
-    __shared__ int64_t wsum[4];
+    __shared__ int64_t base_s;
+    int64_t part = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += tile_sum[t];
+    const int64_t before = block_inclusive_scan_256(part, wsum);
+    if (threadIdx.x == 255) base_s = before;
+    __syncthreads();
+    const int64_t base = base_s;
+    __syncthreads();                               // wsum is reused below
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int64_t v = i < B ? totals[i] : 0;
-    const int64_t inc = block_inclusive_scan_256(v, wsum) + tile_base[blockIdx.x];
+    const int64_t inc = block_inclusive_scan_256(v, wsum) + base;
     if (i < B) row_offsets[i] = inc - v;
     if (i == B - 1) row_offsets[B] = inc;
 }
@@ -338,10 +335,8 @@ int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, doub
     int64_t *tiles = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ctx->d_totals) +
                                                  (((size_t)ctx->totals_cap * 4 + 7) & ~(size_t)7));
     hipLaunchKernelGGL(row_counts_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, wp, B, m, velocity, dt,
-                       times, seg_rows, ctx->d_totals, ctx->d_flags);
-    hipLaunchKernelGGL(tile_sums_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, tiles, n_tiles);
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles,
+                       times, seg_rows, ctx->d_totals, tiles, ctx->d_flags);
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles,
                        row_offsets);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;

@@ -628,7 +628,7 @@ int uavac_rrt_star_dev(uavac_ctx *ctx, const double *start, const double *goal, 
                        const double *samples, const double *cuboids, int n_obs, double *nodes, int32_t *canon,
                        int32_t *parent, int32_t *best_parent, double *best_path, int32_t *counts,
                        double *best_cost) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (!start || !goal || !samples || !nodes || !canon || !parent || !best_parent || !best_path || !counts || !best_cost)
         return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     if (B < 1 || max_iter < 1) return uavac_fail(ctx, UAVAC_EINVAL, "B and max_iter must be >= 1");
@@ -676,7 +676,7 @@ int uavac_rrt_star_dev(uavac_ctx *ctx, const double *start, const double *goal, 
 
 int uavac_rrt_segment_hits_dev(uavac_ctx *ctx, const double *p0, const double *p1, int E, const double *cuboids,
                                int n_obs, int32_t *hit) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (E < 0 || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (E == 0) return UAVAC_OK;
     if (!p0 || !p1 || !hit || (n_obs > 0 && !cuboids)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
@@ -688,7 +688,7 @@ int uavac_rrt_segment_hits_dev(uavac_ctx *ctx, const double *p0, const double *p
 
 int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p1, int p1_is_single, int E,
                                double *out) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (E < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (E == 0) return UAVAC_OK;
     if (!p0 || !p1 || !out) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
@@ -701,7 +701,7 @@ int uavac_rrt_edge_lengths_dev(uavac_ctx *ctx, const double *p0, const double *p
 int uavac_rrt_draw_nodes_dev(uavac_ctx *ctx, const uint32_t *seeds, const double *goals, int B, int n,
                              const double *limits_lw_host, const double *limits_up_host, double epsilon, double *samples,
                              int64_t *consumed) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (B < 1 || n < 1) return uavac_fail(ctx, UAVAC_EINVAL, "B and n must be >= 1");
     if (!seeds || !goals || !limits_lw_host || !limits_up_host || !samples) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     for (int a = 0; a < 3; ++a)
@@ -716,7 +716,7 @@ int uavac_rrt_draw_nodes_dev(uavac_ctx *ctx, const uint32_t *seeds, const double
 
 int uavac_rrt_simplify_dev(uavac_ctx *ctx, const double *paths, const int32_t *lens, int B, int cap, const double *cuboids,
                            int n_obs, double *out_paths, int32_t *out_lens) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (B < 1 || cap < 1 || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "B and cap must be >= 1");
     if (!paths || !lens || !out_paths || !out_lens || (n_obs > 0 && !cuboids)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     hipLaunchKernelGGL(rrt_simplify_kernel, dim3(B), dim3(W), 0, ctx->stream, paths, lens, cap, cuboids, n_obs, out_paths,
@@ -726,7 +726,7 @@ int uavac_rrt_simplify_dev(uavac_ctx *ctx, const double *paths, const int32_t *l
 }
 
 int uavac_rrt_path_cost_dev(uavac_ctx *ctx, const double *path, int n, double *cost) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (n < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (!cost || (n > 0 && !path)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     hipLaunchKernelGGL(rrt_path_cost_kernel, dim3(1), dim3(64), 0, ctx->stream, path, n, cost);
@@ -735,7 +735,7 @@ int uavac_rrt_path_cost_dev(uavac_ctx *ctx, const double *path, int n, double *c
 }
 
 int uavac_rrt_steer_dev(uavac_ctx *ctx, const double *sample, const double *nearest, int E, double step, double *out) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (E < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (E == 0) return UAVAC_OK;
     if (!sample || !nearest || !out) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
@@ -748,7 +748,7 @@ int uavac_rrt_steer_dev(uavac_ctx *ctx, const double *sample, const double *near
 int uavac_rrt_star(uavac_ctx *ctx, const double *start, const double *goal, int B, double step, int max_iter,
                    const double *samples, const double *cuboids, int n_obs, double *nodes, int32_t *canon,
                    int32_t *parent, int32_t *best_parent, double *best_path, int32_t *counts, double *best_cost) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (!start || !goal || !samples || !nodes || !canon || !parent || !best_parent || !best_path || !counts || !best_cost)
         return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     if (B < 1 || max_iter < 1) return uavac_fail(ctx, UAVAC_EINVAL, "B and max_iter must be >= 1");
@@ -790,7 +790,7 @@ int uavac_rrt_star(uavac_ctx *ctx, const double *start, const double *goal, int 
 
 int uavac_rrt_segment_hits(uavac_ctx *ctx, const double *p0, const double *p1, int E, const double *cuboids, int n_obs,
                            int32_t *hit) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (E < 0 || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (E == 0) return UAVAC_OK;
     if (!p0 || !p1 || !hit || (n_obs > 0 && !cuboids)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
@@ -811,7 +811,7 @@ int uavac_rrt_segment_hits(uavac_ctx *ctx, const double *p0, const double *p1, i
 }
 
 int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, int p1_is_single, int E, double *out) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (E < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (E == 0) return UAVAC_OK;
     if (!p0 || !p1 || !out) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
@@ -831,7 +831,7 @@ int uavac_rrt_edge_lengths(uavac_ctx *ctx, const double *p0, const double *p1, i
 
 int uavac_rrt_simplify(uavac_ctx *ctx, const double *paths, const int32_t *lens, int B, int cap, const double *cuboids,
                        int n_obs, double *out_paths, int32_t *out_lens) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (B < 1 || cap < 1 || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "B and cap must be >= 1");
     if (!paths || !lens || !out_paths || !out_lens || (n_obs > 0 && !cuboids)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     for (int b = 0; b < B; ++b)
@@ -855,7 +855,7 @@ int uavac_rrt_simplify(uavac_ctx *ctx, const double *paths, const int32_t *lens,
 }
 
 int uavac_rrt_path_cost(uavac_ctx *ctx, const double *path, int n, double *cost) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (n < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (!cost || (n > 0 && !path)) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     DevBuf dp, dc;
@@ -869,7 +869,7 @@ int uavac_rrt_path_cost(uavac_ctx *ctx, const double *path, int n, double *cost)
 }
 
 int uavac_rrt_steer(uavac_ctx *ctx, const double *sample, const double *nearest, int E, double step, double *out) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (E < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (E == 0) return UAVAC_OK;
     if (!sample || !nearest || !out) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");

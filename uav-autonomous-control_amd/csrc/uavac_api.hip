@@ -4,18 +4,62 @@
 #include "uavac_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
 namespace {
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <class T> T *as() { return static_cast<T *>(p); }
-};
+constexpr size_t kStageChunk = (size_t)8 << 20;       // bytes per half of the pinned ping-pong buffer
+
+// Host <-> device copies of the host-pointer twins.  The caller's buffers are pageable; they travel through the ctx's
+// pinned staging buffer in kStageChunk pieces, two halves in flight: the DMA of one piece overlaps the CPU copy of the
+// next (h2d) or previous (d2h) one.  Ordered on the ctx stream like everything else.
+int h2d_staged(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!bytes) return UAVAC_OK;
+    if (int rc = uavac_pin_reserve(ctx, 2 * kStageChunk)) return rc;
+    const char *src = static_cast<const char *>(src_host);
+    char *dst = static_cast<char *>(dst_dev);
+    size_t i = 0;
+    for (size_t off = 0; off < bytes; off += kStageChunk, ++i) {
+        const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
+        char *half = ctx->h_pin + (i & 1) * kStageChunk;
+        if (i >= 2) UAVAC_HIP(ctx, hipEventSynchronize(ctx->pin_ev[i & 1]));     // the DMA that last read this half
+        std::memcpy(half, src + off, n);
+        UAVAC_HIP(ctx, hipMemcpyAsync(dst + off, half, n, hipMemcpyHostToDevice, ctx->stream));
+        UAVAC_HIP(ctx, hipEventRecord(ctx->pin_ev[i & 1], ctx->stream));
+    }
+    // the halves must not be rewritten by a later call before these DMAs have read them
+    UAVAC_HIP(ctx, hipEventSynchronize(ctx->pin_ev[0]));
+    if (i > 1) UAVAC_HIP(ctx, hipEventSynchronize(ctx->pin_ev[1]));
+    return UAVAC_OK;
+}
+
+int d2h_staged(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!bytes) return UAVAC_OK;
+    if (int rc = uavac_pin_reserve(ctx, 2 * kStageChunk)) return rc;
+    char *dst = static_cast<char *>(dst_host);
+    const char *src = static_cast<const char *>(src_dev);
+    const size_t n_chunks = (bytes + kStageChunk - 1) / kStageChunk;
+    auto len = [&](size_t i) { return (i + 1 < n_chunks) ? kStageChunk : bytes - i * kStageChunk; };
+    auto issue = [&](size_t i) -> int {
+        UAVAC_HIP(ctx, hipMemcpyAsync(ctx->h_pin + (i & 1) * kStageChunk, src + i * kStageChunk, len(i),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        UAVAC_HIP(ctx, hipEventRecord(ctx->pin_ev[i & 1], ctx->stream));
+        return UAVAC_OK;
+    };
+    if (int rc = issue(0)) return rc;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        if (i + 1 < n_chunks)
+            if (int rc = issue(i + 1)) return rc;                        // its half was drained one iteration ago
+        UAVAC_HIP(ctx, hipEventSynchronize(ctx->pin_ev[i & 1]));
+        std::memcpy(dst + i * kStageChunk, ctx->h_pin + (i & 1) * kStageChunk, len(i));
+    }
+    return UAVAC_OK;
+}
+
+template <class T> T *take(uavac_ctx *ctx, size_t count) { return static_cast<T *>(uavac_arena_take(ctx, count * sizeof(T))); }
 
 bool finite_all(const double *p, size_t n) {
     for (size_t i = 0; i < n; ++i)
@@ -31,6 +75,12 @@ int check_plan_args(uavac_ctx *ctx, const void *wp, int B, int m) {
     return UAVAC_OK;
 }
 
+// The device-side flags are sticky until read: the host twins clear them on entry (so that what an earlier _dev call
+// left behind is not reported against valid input) and read-and-clear them on exit.
+int clear_flags(uavac_ctx *ctx) {
+    UAVAC_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), ctx->stream));
+    return UAVAC_OK;
+}
 int read_flags(uavac_ctx *ctx, int32_t out[4]) {
     UAVAC_HIP(ctx, hipMemcpyAsync(out, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     UAVAC_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), ctx->stream));
@@ -39,6 +89,58 @@ int read_flags(uavac_ctx *ctx, int32_t out[4]) {
 }
 
 }  // namespace
+
+int uavac_arena_reserve(uavac_ctx *ctx, size_t bytes) {
+    if (bytes > ctx->arena_cap) {
+        UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));          // nothing enqueued may still use the old block
+        if (ctx->d_arena) UAVAC_HIP(ctx, hipFree(ctx->d_arena));
+        ctx->d_arena = nullptr;
+        ctx->arena_cap = 0;
+        size_t want = bytes + bytes / 4;
+        if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+        void *p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes;
+            UAVAC_HIP(ctx, hipMalloc(&p, want));
+        }
+        ctx->d_arena = static_cast<char *>(p);
+        ctx->arena_cap = want;
+    }
+    ctx->arena_top = 0;
+    return UAVAC_OK;
+}
+
+void *uavac_arena_take(uavac_ctx *ctx, size_t bytes) {
+    const size_t n = uavac_arena_size(bytes ? bytes : 8);
+    if (ctx->arena_top + n > ctx->arena_cap) return nullptr;         // reserve() was given too small a total: a bug
+    void *p = ctx->d_arena + ctx->arena_top;
+    ctx->arena_top += n;
+    return p;
+}
+
+int uavac_scratch(uavac_ctx *ctx, size_t bytes, void **out) {
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(bytes))) return rc;
+    *out = uavac_arena_take(ctx, bytes);
+    return UAVAC_OK;
+}
+
+int uavac_pin_reserve(uavac_ctx *ctx, size_t bytes) {
+    if (!ctx->pin_ev[0]) {
+        UAVAC_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[0], hipEventDisableTiming));
+        UAVAC_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[1], hipEventDisableTiming));
+    }
+    if (bytes <= ctx->pin_cap) return UAVAC_OK;
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pin) UAVAC_HIP(ctx, hipHostFree(ctx->h_pin));
+    ctx->h_pin = nullptr;
+    ctx->pin_cap = 0;
+    void *p = nullptr;
+    UAVAC_HIP(ctx, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    ctx->h_pin = static_cast<char *>(p);
+    ctx->pin_cap = bytes;
+    return UAVAC_OK;
+}
 
 VehK uavac_make_vehk(const uavac_vehicle &V) {
     VehK k{};
@@ -84,9 +186,14 @@ int uavac_create(uavac_ctx **out, int device_id) {
     uavac_ctx *ctx = new (std::nothrow) uavac_ctx();
     if (!ctx) return UAVAC_ENOMEM;
     if (device_id >= 0) {
-        if (device_id >= ndev || hipSetDevice(device_id) != hipSuccess) { delete ctx; return UAVAC_EHIP; }
+        if (device_id >= ndev) { delete ctx; return UAVAC_EHIP; }
         ctx->device = device_id;
     } else if (hipGetDevice(&ctx->device) != hipSuccess) { delete ctx; return UAVAC_EHIP; }
+    uavac_device_guard guard(ctx);                // stream and buffers are created on the ctx's device
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) { delete ctx; return UAVAC_EHIP; }
+    }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return UAVAC_EHIP; }
     ctx->stream = ctx->own_stream;
     if (hipMalloc(&ctx->d_flags, 4 * sizeof(int32_t)) != hipSuccess ||
@@ -95,16 +202,23 @@ int uavac_create(uavac_ctx **out, int device_id) {
         delete ctx;
         return UAVAC_EHIP;
     }
+    if (const char *e = getenv("UAVAC_ROLLOUT_SHAPE")) ctx->rollout_shape = (e[0] == '4') ? 4 : 1;
+    if (const char *e = getenv("UAVAC_ROLLOUT_ALIGN")) ctx->rollout_align = (e[0] == '0') ? 0 : 1;
     *out = ctx;
     return UAVAC_OK;
 }
 
 void uavac_destroy(uavac_ctx *ctx) {
     if (!ctx) return;
+    uavac_device_guard guard(ctx);
     (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_totals) (void)hipFree(ctx->d_totals);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_arena) (void)hipFree(ctx->d_arena);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (hipEvent_t e : ctx->pin_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -124,9 +238,33 @@ int uavac_reset_stream(uavac_ctx *ctx) {
 }
 
 int uavac_synchronize(uavac_ctx *ctx) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
+}
+
+int uavac_device(const uavac_ctx *ctx) { return ctx ? ctx->device : UAVAC_EINVAL; }
+
+int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
+    if (!ctx || !name) return UAVAC_EINVAL;
+    const std::string n(name);
+    if (n == "rollout_shape") {
+        if (value != 1 && value != 4) return uavac_fail(ctx, UAVAC_EINVAL, "rollout_shape is 1 or 4");
+        ctx->rollout_shape = value;
+    } else if (n == "rollout_align") {
+        ctx->rollout_align = value ? 1 : 0;
+    } else {
+        return uavac_fail(ctx, UAVAC_EINVAL, "unknown option");
+    }
+    return UAVAC_OK;
+}
+
+const char *uavac_last_rollout_kernel(const uavac_ctx *ctx) { return ctx ? ctx->last_rollout.c_str() : ""; }
+
+int uavac_take_flags(uavac_ctx *ctx, int32_t flags[4]) {
+    UAVAC_ENTER(ctx);
+    if (!flags) return uavac_fail(ctx, UAVAC_EINVAL, "null flags");
+    return read_flags(ctx, flags);
 }
 
 void uavac_vehicle_default(uavac_vehicle *V) {
@@ -148,6 +286,7 @@ void uavac_vehicle_default(uavac_vehicle *V) {
 // ------------------------------------------------------------------------------- planning, device
 int uavac_minsnap_row_counts_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                                  double *times, int32_t *seg_rows, int64_t *row_offsets) {
+    UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
     if (!times || !seg_rows || !row_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "null output pointer");
     if (!std::isfinite(velocity) || !std::isfinite(dt)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite velocity or dt");
@@ -157,6 +296,7 @@ int uavac_minsnap_row_counts_dev(uavac_ctx *ctx, const double *wp, int B, int m,
 
 int uavac_minsnap_solve_dev(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                             int32_t *status) {
+    UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
     if (!times || !coeffs) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     return uavac_launch_solve_bt(ctx, wp, times, B, m, coeffs, status);
@@ -164,85 +304,138 @@ int uavac_minsnap_solve_dev(uavac_ctx *ctx, const double *wp, const double *time
 
 int uavac_minsnap_solve_banded_dev(uavac_ctx *ctx, const double *wp, const double *times, int B, int m,
                                    double *coeffs, int32_t *status) {
+    UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
     if (!times || !coeffs) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     return uavac_launch_solve(ctx, wp, times, B, m, coeffs, status);
 }
 
-int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double *times, const int32_t *seg_rows,
-                             const int64_t *row_offsets, int B, int m, double dt, double *traj) {
-    (void)times;
+static int check_sample_args(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
+                             int B, int m, double dt, const double *traj) {
     if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
     if (!seg_rows || !row_offsets || !traj) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
-    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj);
+    return UAVAC_OK;
+}
+
+int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double *times, const int32_t *seg_rows,
+                             const int64_t *row_offsets, int B, int m, double dt, double *traj) {
+    (void)times;
+    UAVAC_ENTER(ctx);
+    if (int rc = check_sample_args(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj)) return rc;
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, SampleExtras{});
 }
 
 int uavac_minsnap_sample_yaw_dev(uavac_ctx *ctx, const double *coeffs, const double *times, const int32_t *seg_rows,
                                  const int64_t *row_offsets, int B, int m, double dt, double *traj, double *yaw) {
     (void)times;
-    if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
-    if (!seg_rows || !row_offsets || !traj || !yaw) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
-    if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
-    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, nullptr, nullptr, yaw);
+    UAVAC_ENTER(ctx);
+    if (int rc = check_sample_args(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj)) return rc;
+    if (!yaw) return uavac_fail(ctx, UAVAC_EINVAL, "null yaw");
+    SampleExtras x;
+    x.yaw_dense = yaw;
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
 }
 
 int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const double *times, const int32_t *seg_rows,
                                   const int64_t *row_offsets, int B, int m, double dt, double *traj,
                                   const double *aabb, int32_t *hit) {
     (void)times;
-    if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
-    if (!seg_rows || !row_offsets || !traj || !aabb || !hit) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
-    if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
-    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, aabb, hit);
+    UAVAC_ENTER(ctx);
+    if (int rc = check_sample_args(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj)) return rc;
+    if (!aabb || !hit) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    SampleExtras x;
+    x.aabb = aabb;
+    x.hit = hit;
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
+}
+
+int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows,
+                                    const int64_t *row_offsets, int B, int m, double dt, double *traj, double *yaw,
+                                    double *jerk, double *snap) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_sample_args(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj)) return rc;
+    SampleExtras x;
+    x.yaw_dense = yaw;
+    x.jerk = jerk;
+    x.snap = snap;
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
+}
+
+int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt, double *times,
+                           int32_t *seg_rows, int64_t *row_offsets, double *coeffs, int32_t *status, double *traj,
+                           int64_t traj_capacity_rows, double *yaw) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
+    if (!times || !seg_rows || !row_offsets || !coeffs || !traj) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (!std::isfinite(velocity) || !std::isfinite(dt)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite velocity or dt");
+    if (!(velocity > 0.0) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity and dt must be > 0");
+    if (traj_capacity_rows < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative capacity");
+    // the whole chain enqueued from here: nothing returns to the caller (or to an interpreter) between the launches
+    if (int rc = uavac_launch_row_counts(ctx, wp, B, m, velocity, dt, times, seg_rows, row_offsets)) return rc;
+    if (int rc = uavac_launch_solve_bt(ctx, wp, times, B, m, coeffs, status)) return rc;
+    SampleExtras x;
+    x.yaw_dense = yaw;
+    x.capacity_rows = traj_capacity_rows;         // the sampler refuses (flag 2) instead of overrunning the buffer
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
+}
+
+int uavac_yaw_scan_dev(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B, double *yaws) {
+    UAVAC_ENTER(ctx);
+    if (!velocities || !offsets || !yaws || B < 1) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    return uavac_launch_yaw_scan(ctx, velocities, offsets, B, yaws);
 }
 
 // --------------------------------------------------------------------------------- planning, host
 int uavac_minsnap_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                              double *times, int32_t *seg_rows, int64_t *row_offsets) {
+    UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
     if (!row_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "null row_offsets");
     const size_t nwp = (size_t)B * (m + 1) * 3, nseg = (size_t)B * m;
     if (!finite_all(wp, nwp) || !std::isfinite(velocity) || !std::isfinite(dt))
         return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite waypoint, velocity or dt");
-    DevBuf dwp, dt_, dsr, dro;
-    UAVAC_HIP(ctx, dwp.alloc(nwp * 8));
-    UAVAC_HIP(ctx, dt_.alloc(nseg * 8));
-    UAVAC_HIP(ctx, dsr.alloc(nseg * 4));
-    UAVAC_HIP(ctx, dro.alloc(((size_t)B + 1) * 8));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dwp.p, wp, nwp * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = uavac_minsnap_row_counts_dev(ctx, dwp.as<double>(), B, m, velocity, dt, dt_.as<double>(),
-                                              dsr.as<int32_t>(), dro.as<int64_t>())) return rc;
-    if (times) UAVAC_HIP(ctx, hipMemcpyAsync(times, dt_.p, nseg * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (seg_rows) UAVAC_HIP(ctx, hipMemcpyAsync(seg_rows, dsr.p, nseg * 4, hipMemcpyDeviceToHost, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(row_offsets, dro.p, ((size_t)B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(nwp * 8) + uavac_arena_size(nseg * 8) +
+                                              uavac_arena_size(nseg * 4) + uavac_arena_size(((size_t)B + 1) * 8))) return rc;
+    double *dwp = take<double>(ctx, nwp), *dt_ = take<double>(ctx, nseg);
+    int32_t *dsr = take<int32_t>(ctx, nseg);
+    int64_t *dro = take<int64_t>(ctx, (size_t)B + 1);
+    if (int rc = clear_flags(ctx)) return rc;
+    if (int rc = h2d_staged(ctx, dwp, wp, nwp * 8)) return rc;
+    if (int rc = uavac_minsnap_row_counts_dev(ctx, dwp, B, m, velocity, dt, dt_, dsr, dro)) return rc;
+    if (times) if (int rc = d2h_staged(ctx, times, dt_, nseg * 8)) return rc;
+    if (seg_rows) if (int rc = d2h_staged(ctx, seg_rows, dsr, nseg * 4)) return rc;
+    if (int rc = d2h_staged(ctx, row_offsets, dro, ((size_t)B + 1) * 8)) return rc;
     int32_t fl[4];
     if (int rc = read_flags(ctx, fl)) return rc;
     if (fl[0]) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite segment duration");
+    if (fl[3]) return uavac_fail(ctx, UAVAC_EINVAL, "a mission has more than 2^31-1 rows");
     return UAVAC_OK;
 }
 
 int uavac_minsnap_solve(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double *coeffs,
                         double *times) {
+    UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
     if (!coeffs) return uavac_fail(ctx, UAVAC_EINVAL, "null coeffs");
     const size_t nwp = (size_t)B * (m + 1) * 3, nseg = (size_t)B * m, nco = (size_t)B * 24 * m;
     if (!finite_all(wp, nwp) || !std::isfinite(velocity))
         return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite waypoint or velocity");
     if (!(velocity > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity must be > 0");
-    DevBuf dwp, dt_, dsr, dro, dco;
-    UAVAC_HIP(ctx, dwp.alloc(nwp * 8));
-    UAVAC_HIP(ctx, dt_.alloc(nseg * 8));
-    UAVAC_HIP(ctx, dsr.alloc(nseg * 4));
-    UAVAC_HIP(ctx, dro.alloc(((size_t)B + 1) * 8));
-    UAVAC_HIP(ctx, dco.alloc(nco * 8));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dwp.p, wp, nwp * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(nwp * 8) + uavac_arena_size(nseg * 8) +
+                                              uavac_arena_size(nseg * 4) + uavac_arena_size(((size_t)B + 1) * 8) +
+                                              uavac_arena_size(nco * 8))) return rc;
+    double *dwp = take<double>(ctx, nwp), *dt_ = take<double>(ctx, nseg);
+    int32_t *dsr = take<int32_t>(ctx, nseg);
+    int64_t *dro = take<int64_t>(ctx, (size_t)B + 1);
+    double *dco = take<double>(ctx, nco);
+    if (int rc = clear_flags(ctx)) return rc;
+    if (int rc = h2d_staged(ctx, dwp, wp, nwp * 8)) return rc;
     // dt only shapes the row counts, which this entry point does not return
-    if (int rc = uavac_launch_row_counts(ctx, dwp.as<double>(), B, m, velocity, 1.0, dt_.as<double>(),
-                                         dsr.as<int32_t>(), dro.as<int64_t>())) return rc;
-    if (int rc = uavac_launch_solve_bt(ctx, dwp.as<double>(), dt_.as<double>(), B, m, dco.as<double>(), nullptr)) return rc;
-    UAVAC_HIP(ctx, hipMemcpyAsync(coeffs, dco.p, nco * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (times) UAVAC_HIP(ctx, hipMemcpyAsync(times, dt_.p, nseg * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = uavac_launch_row_counts(ctx, dwp, B, m, velocity, 1.0, dt_, dsr, dro)) return rc;
+    if (int rc = uavac_launch_solve_bt(ctx, dwp, dt_, B, m, dco, nullptr)) return rc;
+    if (int rc = d2h_staged(ctx, coeffs, dco, nco * 8)) return rc;
+    if (times) if (int rc = d2h_staged(ctx, times, dt_, nseg * 8)) return rc;
     int32_t fl[4];
     if (int rc = read_flags(ctx, fl)) return rc;
     if (fl[0]) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite segment duration");
@@ -252,6 +445,7 @@ int uavac_minsnap_solve(uavac_ctx *ctx, const double *wp, int B, int m, double v
 
 int uavac_minsnap_sample(uavac_ctx *ctx, const double *coeffs, const double *times, int B, int m, double dt,
                          const int64_t *row_offsets, double *traj) {
+    UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
     if (!times || !row_offsets || !traj) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
@@ -271,17 +465,35 @@ int uavac_minsnap_sample(uavac_ctx *ctx, const double *coeffs, const double *tim
     }
     const int64_t total = row_offsets[B] - row_offsets[0];
     if (row_offsets[0] != 0 || total < 0) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must start at 0");
-    DevBuf dco, dsr, dro, dtr;
-    UAVAC_HIP(ctx, dco.alloc(nco * 8));
-    UAVAC_HIP(ctx, dsr.alloc(nseg * 4));
-    UAVAC_HIP(ctx, dro.alloc(((size_t)B + 1) * 8));
-    UAVAC_HIP(ctx, dtr.alloc((size_t)total * UAVAC_TRAJ_COLS * 8));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dco.p, coeffs, nco * 8, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dsr.p, sr.data(), nseg * 4, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dro.p, row_offsets, ((size_t)B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = uavac_launch_sample(ctx, dco.as<double>(), dsr.as<int32_t>(), dro.as<int64_t>(), B, m, dt,
-                                     dtr.as<double>())) return rc;
-    UAVAC_HIP(ctx, hipMemcpyAsync(traj, dtr.p, (size_t)total * UAVAC_TRAJ_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t ntr = (size_t)total * UAVAC_TRAJ_COLS;
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(nco * 8) + uavac_arena_size(nseg * 4) +
+                                              uavac_arena_size(((size_t)B + 1) * 8) + uavac_arena_size(ntr * 8))) return rc;
+    double *dco = take<double>(ctx, nco);
+    int32_t *dsr = take<int32_t>(ctx, nseg);
+    int64_t *dro = take<int64_t>(ctx, (size_t)B + 1);
+    double *dtr = take<double>(ctx, ntr);
+    if (int rc = h2d_staged(ctx, dco, coeffs, nco * 8)) return rc;
+    if (int rc = h2d_staged(ctx, dsr, sr.data(), nseg * 4)) return rc;
+    if (int rc = h2d_staged(ctx, dro, row_offsets, ((size_t)B + 1) * 8)) return rc;
+    if (int rc = uavac_launch_sample(ctx, dco, dsr, dro, B, m, dt, dtr, SampleExtras{})) return rc;
+    if (int rc = d2h_staged(ctx, traj, dtr, ntr * 8)) return rc;
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UAVAC_OK;
+}
+
+int uavac_yaw_scan(uavac_ctx *ctx, const double *velocities, int64_t n, double *yaws) {
+    UAVAC_ENTER(ctx);
+    if (n < 0 || (n > 0 && (!velocities || !yaws))) return uavac_fail(ctx, UAVAC_EINVAL, "bad n or null pointer");
+    if (n == 0) return UAVAC_OK;
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size((size_t)n * 24) + uavac_arena_size((size_t)n * 8) +
+                                              uavac_arena_size(16))) return rc;
+    double *dv = take<double>(ctx, (size_t)n * 3), *dy = take<double>(ctx, (size_t)n);
+    int64_t *doff = take<int64_t>(ctx, 2);
+    const int64_t off[2] = {0, n};
+    if (int rc = h2d_staged(ctx, dv, velocities, (size_t)n * 24)) return rc;
+    if (int rc = h2d_staged(ctx, doff, off, 16)) return rc;
+    if (int rc = uavac_launch_yaw_scan(ctx, dv, doff, 1, dy)) return rc;
+    if (int rc = d2h_staged(ctx, yaws, dy, (size_t)n * 8)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }
@@ -289,7 +501,7 @@ int uavac_minsnap_sample(uavac_ctx *ctx, const double *coeffs, const double *tim
 // -------------------------------------------------------------------------------- control, device
 int uavac_state_init_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *positions, int B, int hover,
                          double *state, int32_t *istate) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (B < 1 || !state || !istate) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null state");
     return uavac_launch_state_init(ctx, uavac_make_vehk(*V), positions, B, hover, state, istate);
@@ -298,7 +510,7 @@ int uavac_state_init_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *p
 int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,
                               double *state, int32_t *istate, int B, int K, double *state_log, double *cmd_log,
                               const double *aabbs, int n_obs) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (B < 1 || K < 0 || !traj || !row_offsets || !state || !istate || n_obs < 0)
         return uavac_fail(ctx, UAVAC_EINVAL, "bad size or null pointer");
@@ -311,7 +523,7 @@ int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const
                                    const int64_t *row_offsets, const double *yaw, int m, double dt, double *state,
                                    int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,
                                    int n_obs) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
     if (K < 0 || !seg_rows || !row_offsets || !yaw || !state || !istate || n_obs < 0)
@@ -332,20 +544,19 @@ int uavac_control_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double 
 // ---------------------------------------------------------------------------------- control, host
 int uavac_state_init(uavac_ctx *ctx, const uavac_vehicle *V, const double *positions, int B, int hover,
                      double *state, int32_t *istate) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (B < 1 || !state || !istate) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null state");
     if (positions && !finite_all(positions, (size_t)B * 3)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite position");
-    DevBuf dp, ds, di;
-    UAVAC_HIP(ctx, ds.alloc((size_t)B * UAVAC_STATE_ROWS * 8));
-    UAVAC_HIP(ctx, di.alloc((size_t)B * UAVAC_ISTATE_ROWS * 4));
-    if (positions) {
-        UAVAC_HIP(ctx, dp.alloc((size_t)B * 24));
-        UAVAC_HIP(ctx, hipMemcpyAsync(dp.p, positions, (size_t)B * 24, hipMemcpyHostToDevice, ctx->stream));
-    }
-    if (int rc = uavac_state_init_dev(ctx, V, positions ? dp.as<double>() : nullptr, B, hover, ds.as<double>(),
-                                      di.as<int32_t>())) return rc;
-    UAVAC_HIP(ctx, hipMemcpyAsync(state, ds.p, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyDeviceToHost, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(istate, di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t ns = (size_t)B * UAVAC_STATE_ROWS, ni = (size_t)B * UAVAC_ISTATE_ROWS;
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(ns * 8) + uavac_arena_size(ni * 4) +
+                                              uavac_arena_size((size_t)B * 24))) return rc;
+    double *ds = take<double>(ctx, ns);
+    int32_t *di = take<int32_t>(ctx, ni);
+    double *dp = positions ? take<double>(ctx, (size_t)B * 3) : nullptr;
+    if (positions) if (int rc = h2d_staged(ctx, dp, positions, (size_t)B * 24)) return rc;
+    if (int rc = uavac_state_init_dev(ctx, V, dp, B, hover, ds, di)) return rc;
+    if (int rc = d2h_staged(ctx, state, ds, ns * 8)) return rc;
+    if (int rc = d2h_staged(ctx, istate, di, ni * 4)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }
@@ -353,7 +564,7 @@ int uavac_state_init(uavac_ctx *ctx, const uavac_vehicle *V, const double *posit
 int uavac_control_rollout(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,
                           double *state, int32_t *istate, int B, int K, double *state_log, double *cmd_log,
                           const double *aabbs, int n_obs) {
-    if (!ctx) return UAVAC_EINVAL;
+    UAVAC_ENTER(ctx);
     if (B < 1 || K < 0 || !traj || !row_offsets || !state || !istate || n_obs < 0)
         return uavac_fail(ctx, UAVAC_EINVAL, "bad size or null pointer");
     if (row_offsets[0] != 0) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must start at 0");
@@ -361,29 +572,30 @@ int uavac_control_rollout(uavac_ctx *ctx, const uavac_vehicle *V, const double *
         if (row_offsets[b + 1] < row_offsets[b]) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must be non-decreasing");
     const size_t total = (size_t)row_offsets[B];
     if (!finite_all(state, (size_t)B * UAVAC_STATE_ROWS)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite state");
-    DevBuf dtr, dro, ds, di, dsl, dcl, dab;
-    UAVAC_HIP(ctx, dtr.alloc(total * UAVAC_TRAJ_COLS * 8));
-    UAVAC_HIP(ctx, dro.alloc(((size_t)B + 1) * 8));
-    UAVAC_HIP(ctx, ds.alloc((size_t)B * UAVAC_STATE_ROWS * 8));
-    UAVAC_HIP(ctx, di.alloc((size_t)B * UAVAC_ISTATE_ROWS * 4));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dtr.p, traj, total * UAVAC_TRAJ_COLS * 8, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dro.p, row_offsets, ((size_t)B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(ds.p, state, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(di.p, istate, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (state_log) UAVAC_HIP(ctx, dsl.alloc((size_t)K * 13 * B * 8));
-    if (cmd_log) UAVAC_HIP(ctx, dcl.alloc((size_t)K * UAVAC_CMD_COLS * B * 8));
-    if (aabbs && n_obs > 0) {
-        UAVAC_HIP(ctx, dab.alloc((size_t)n_obs * 48));
-        UAVAC_HIP(ctx, hipMemcpyAsync(dab.p, aabbs, (size_t)n_obs * 48, hipMemcpyHostToDevice, ctx->stream));
-    }
-    if (int rc = uavac_control_rollout_dev(ctx, V, dtr.as<double>(), dro.as<int64_t>(), ds.as<double>(),
-                                           di.as<int32_t>(), B, K, state_log ? dsl.as<double>() : nullptr,
-                                           cmd_log ? dcl.as<double>() : nullptr,
-                                           (aabbs && n_obs > 0) ? dab.as<double>() : nullptr, n_obs)) return rc;
-    UAVAC_HIP(ctx, hipMemcpyAsync(state, ds.p, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyDeviceToHost, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(istate, di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (state_log) UAVAC_HIP(ctx, hipMemcpyAsync(state_log, dsl.p, (size_t)K * 13 * B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (cmd_log) UAVAC_HIP(ctx, hipMemcpyAsync(cmd_log, dcl.p, (size_t)K * UAVAC_CMD_COLS * B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t ntr = total * UAVAC_TRAJ_COLS, ns = (size_t)B * UAVAC_STATE_ROWS, ni = (size_t)B * UAVAC_ISTATE_ROWS;
+    const size_t nsl = state_log ? (size_t)K * 13 * B : 0, ncl = cmd_log ? (size_t)K * UAVAC_CMD_COLS * B : 0;
+    const bool obs = aabbs && n_obs > 0;
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(ntr * 8) + uavac_arena_size(((size_t)B + 1) * 8) +
+                                              uavac_arena_size(ns * 8) + uavac_arena_size(ni * 4) +
+                                              uavac_arena_size(nsl * 8) + uavac_arena_size(ncl * 8) +
+                                              uavac_arena_size((size_t)n_obs * 48))) return rc;
+    double *dtr = take<double>(ctx, ntr);
+    int64_t *dro = take<int64_t>(ctx, (size_t)B + 1);
+    double *ds = take<double>(ctx, ns);
+    int32_t *di = take<int32_t>(ctx, ni);
+    double *dsl = state_log ? take<double>(ctx, nsl) : nullptr;
+    double *dcl = cmd_log ? take<double>(ctx, ncl) : nullptr;
+    double *dab = obs ? take<double>(ctx, (size_t)n_obs * 6) : nullptr;
+    if (int rc = h2d_staged(ctx, dtr, traj, ntr * 8)) return rc;
+    if (int rc = h2d_staged(ctx, dro, row_offsets, ((size_t)B + 1) * 8)) return rc;
+    if (int rc = h2d_staged(ctx, ds, state, ns * 8)) return rc;
+    if (int rc = h2d_staged(ctx, di, istate, ni * 4)) return rc;
+    if (obs) if (int rc = h2d_staged(ctx, dab, aabbs, (size_t)n_obs * 48)) return rc;
+    if (int rc = uavac_control_rollout_dev(ctx, V, dtr, dro, ds, di, B, K, dsl, dcl, dab, obs ? n_obs : 0)) return rc;
+    if (int rc = d2h_staged(ctx, state, ds, ns * 8)) return rc;
+    if (int rc = d2h_staged(ctx, istate, di, ni * 4)) return rc;
+    if (state_log) if (int rc = d2h_staged(ctx, state_log, dsl, nsl * 8)) return rc;
+    if (cmd_log) if (int rc = d2h_staged(ctx, cmd_log, dcl, ncl * 8)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }

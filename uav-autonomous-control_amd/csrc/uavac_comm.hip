@@ -1,0 +1,173 @@
+// Multi-GPU side of the C ABI: the ONE exchange of the path -- the final gather of the ragged
+// trajectory row blocks to a root rank -- over RCCL point-to-point operations on xGMI.
+//
+// One process per GPU, one uavac_ctx each; missions are sharded by contiguous index blocks and every kernel works on
+// its own shard, so nothing is exchanged while planning or flying.  At the end every peer owns one direct xGMI link
+// to the root: ncclGroupStart + one ncclRecv per peer on the root / one ncclSend on each peer + ncclGroupEnd
+// (rccl.h:700,722,923) lets the 7 transfers of an 8-GPU node run concurrently, each on its own link.  A ring
+// all-gather would push 7/8 of the total through every link and deliver to ranks that do not want the data.
+// (The reference has no counterpart: it plans and flies one mission per process, uav_ac/main.py:87-120.)
+
+#include "uavac_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <vector>
+
+namespace {
+
+int nccl_fail(uavac_ctx *ctx, const char *what, ncclResult_t r) {
+    ctx->err = std::string(what) + ": " + ncclGetErrorString(r);
+    return UAVAC_ECOMM;
+}
+
+#define UAVAC_NCCL(ctx, call)                                                                    \
+    do {                                                                                         \
+        ncclResult_t r_ = (call);                                                                \
+        if (r_ != ncclSuccess) return nccl_fail((ctx), #call, r_);                               \
+    } while (0)
+
+// After the operations of a group have been enqueued and the stream has drained: did the communicator see an
+// asynchronous failure (a peer that died, a transport error)?
+int check_async(uavac_ctx *ctx, ncclComm_t comm) {
+    ncclResult_t async = ncclSuccess;
+    UAVAC_NCCL(ctx, ncclCommGetAsyncError(comm, &async));
+    if (async != ncclSuccess) return nccl_fail(ctx, "asynchronous RCCL error", async);
+    return UAVAC_OK;
+}
+
+int comm_shape(uavac_ctx *ctx, ncclComm_t comm, int *world, int *rank) {
+    UAVAC_NCCL(ctx, ncclCommCount(comm, world));
+    UAVAC_NCCL(ctx, ncclCommUserRank(comm, rank));
+    return UAVAC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uavac_comm_unique_id(uavac_ctx *ctx, char id[UAVAC_COMM_ID_BYTES]) {
+    UAVAC_ENTER(ctx);
+    if (!id) return uavac_fail(ctx, UAVAC_EINVAL, "null id");
+    static_assert(UAVAC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "uavac.h and rccl.h disagree on the id size");
+    ncclUniqueId u;
+    UAVAC_NCCL(ctx, ncclGetUniqueId(&u));
+    std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return UAVAC_OK;
+}
+
+int uavac_comm_init_rank(uavac_ctx *ctx, const char id[UAVAC_COMM_ID_BYTES], int world, int rank, void **nccl_comm) {
+    UAVAC_ENTER(ctx);
+    if (!id || !nccl_comm) return uavac_fail(ctx, UAVAC_EINVAL, "null id or output pointer");
+    if (world < 1 || rank < 0 || rank >= world) return uavac_fail(ctx, UAVAC_EINVAL, "need 0 <= rank < world");
+    *nccl_comm = nullptr;
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    UAVAC_NCCL(ctx, ncclCommInitRank(&comm, world, u, rank));     // binds to the current device = ctx->device
+    *nccl_comm = comm;
+    return UAVAC_OK;
+}
+
+int uavac_comm_destroy(uavac_ctx *ctx, void *nccl_comm) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm) return UAVAC_OK;
+    UAVAC_NCCL(ctx, ncclCommDestroy(static_cast<ncclComm_t>(nccl_comm)));
+    return UAVAC_OK;
+}
+
+int uavac_comm_abort(uavac_ctx *ctx, void *nccl_comm) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm) return UAVAC_OK;
+    UAVAC_NCCL(ctx, ncclCommAbort(static_cast<ncclComm_t>(nccl_comm)));
+    return UAVAC_OK;
+}
+
+int uavac_comm_shape(uavac_ctx *ctx, void *nccl_comm, int *world, int *rank) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm || !world || !rank) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    return comm_shape(ctx, static_cast<ncclComm_t>(nccl_comm), world, rank);
+}
+
+int uavac_gather_counts(uavac_ctx *ctx, void *nccl_comm, int64_t n_rows, int64_t *counts) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm || !counts) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (n_rows < 0) return uavac_fail(ctx, UAVAC_EINVAL, "n_rows must be >= 0");
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    int world = 0, rank = 0;
+    if (int rc = comm_shape(ctx, comm, &world, &rank)) return rc;
+    int64_t *d = nullptr;                                          // [1 + world] i64 of device scratch
+    if (int rc = uavac_scratch(ctx, (size_t)(1 + world) * 8, reinterpret_cast<void **>(&d))) return rc;
+    UAVAC_HIP(ctx, hipMemcpyAsync(d, &n_rows, 8, hipMemcpyHostToDevice, ctx->stream));
+    UAVAC_NCCL(ctx, ncclAllGather(d, d + 1, 1, ncclInt64, comm, ctx->stream));
+    UAVAC_HIP(ctx, hipMemcpyAsync(counts, d + 1, (size_t)world * 8, hipMemcpyDeviceToHost, ctx->stream));
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return check_async(ctx, comm);
+}
+
+int uavac_gather_rows_dev(uavac_ctx *ctx, void *nccl_comm, const double *rows, int64_t n_rows, int row_elems,
+                          const int64_t *counts, int root, double *out) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm || !counts) return uavac_fail(ctx, UAVAC_EINVAL, "null communicator or counts");
+    if (row_elems < 1 || n_rows < 0) return uavac_fail(ctx, UAVAC_EINVAL, "bad row shape");
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    int world = 0, rank = 0;
+    if (int rc = comm_shape(ctx, comm, &world, &rank)) return rc;
+    if (root < 0 || root >= world) return uavac_fail(ctx, UAVAC_EINVAL, "root out of range");
+    for (int r = 0; r < world; ++r)
+        if (counts[r] < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
+    if (counts[rank] != n_rows) return uavac_fail(ctx, UAVAC_EINVAL, "counts[rank] != n_rows");
+    if (n_rows > 0 && !rows) return uavac_fail(ctx, UAVAC_EINVAL, "null rows");
+    const size_t re = (size_t)row_elems;
+    if (rank == root) {
+        if (!out) return uavac_fail(ctx, UAVAC_EINVAL, "null out on the root");
+        std::vector<size_t> off((size_t)world + 1, 0);
+        for (int r = 0; r < world; ++r) off[r + 1] = off[r] + (size_t)counts[r];
+        if (n_rows > 0 && out + off[rank] * re != rows)            // the root's own block: a device-to-device copy
+            UAVAC_HIP(ctx, hipMemcpyAsync(out + off[rank] * re, rows, (size_t)n_rows * re * 8, hipMemcpyDeviceToDevice,
+                                          ctx->stream));
+        // one grouped launch: the receives run concurrently, one per direct xGMI link into the root
+        UAVAC_NCCL(ctx, ncclGroupStart());
+        for (int r = 0; r < world; ++r) {
+            if (r == root || counts[r] == 0) continue;
+            ncclResult_t res = ncclRecv(out + off[r] * re, (size_t)counts[r] * re, ncclDouble, r, comm, ctx->stream);
+            if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclRecv", res); }
+        }
+        UAVAC_NCCL(ctx, ncclGroupEnd());
+    } else if (n_rows > 0) {
+        UAVAC_NCCL(ctx, ncclGroupStart());
+        ncclResult_t res = ncclSend(rows, (size_t)n_rows * re, ncclDouble, root, comm, ctx->stream);
+        if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclSend", res); }
+        UAVAC_NCCL(ctx, ncclGroupEnd());
+    }
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;                    // enqueued on the ctx stream; uavac_comm_finish() synchronises and checks
+}
+
+int uavac_comm_finish(uavac_ctx *ctx, void *nccl_comm) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm) return uavac_fail(ctx, UAVAC_EINVAL, "null communicator");
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return check_async(ctx, static_cast<ncclComm_t>(nccl_comm));
+}
+
+int uavac_comm_loopback_dev(uavac_ctx *ctx, void *nccl_comm, const double *src, double *dst, int64_t n) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm || !src || !dst || n < 1) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer or n < 1");
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    int world = 0, rank = 0;
+    if (int rc = comm_shape(ctx, comm, &world, &rank)) return rc;
+    // the very pair of calls the gather uses, with this rank as its own peer: exercises RCCL's send/recv path on
+    // a single GPU (a self send/recv must sit in one group)
+    UAVAC_NCCL(ctx, ncclGroupStart());
+    ncclResult_t a = ncclSend(src, (size_t)n, ncclDouble, rank, comm, ctx->stream);
+    ncclResult_t b = ncclRecv(dst, (size_t)n, ncclDouble, rank, comm, ctx->stream);
+    ncclResult_t e = ncclGroupEnd();
+    if (a != ncclSuccess) return nccl_fail(ctx, "ncclSend (loopback)", a);
+    if (b != ncclSuccess) return nccl_fail(ctx, "ncclRecv (loopback)", b);
+    if (e != ncclSuccess) return nccl_fail(ctx, "ncclGroupEnd (loopback)", e);
+    return UAVAC_OK;
+}
+
+}  // extern "C"

@@ -18,8 +18,38 @@ struct uavac_ctx {
     size_t totals_cap = 0;
     double *d_ws = nullptr;          // block-Thomas workspace [m-1][28][B]
     size_t ws_cap = 0;               // in doubles
+    // Device scratch of the host-pointer twins and small internal temporaries: one arena, grown on demand and kept,
+    // handed out by bump allocation inside one entry point (uavac_arena_reserve, then uavac_arena_take).  Reuse across
+    // calls is ordered by the ctx stream.
+    char *d_arena = nullptr;
+    size_t arena_cap = 0, arena_top = 0;
+    // Pinned host staging (hipHostMalloc) of the host-pointer twins: two halves used as a ping-pong pipeline.
+    char *h_pin = nullptr;
+    size_t pin_cap = 0;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::string err;
+    int rollout_shape = 1;           // tuning (uavac_set_option): workgroup shape of logged rollout launches, 1 or 4
+    int rollout_align = 1;           // tuning: launch the 2-wave aligner kernel before a logged launch of shape 1
+    std::string last_rollout;        // name and template arguments of the rollout kernel launched last (diagnostics)
 };
+
+// Every entry point that launches, allocates or copies runs with the ctx's device current and puts the caller's
+// device back on return: a ctx created for GPU 1 must work while GPU 0 is the thread's current device.
+struct uavac_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit uavac_device_guard(const uavac_ctx *ctx) {
+        if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~uavac_device_guard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    uavac_device_guard(const uavac_device_guard &) = delete;
+    uavac_device_guard &operator=(const uavac_device_guard &) = delete;
+};
+#define UAVAC_ENTER(ctx)                \
+    if (!(ctx)) return UAVAC_EINVAL;    \
+    uavac_device_guard uavac_guard_(ctx)
 
 #define UAVAC_HIP(ctx, call)                                                                     \
     do {                                                                                         \
@@ -61,6 +91,16 @@ __device__ __forceinline__ int xcd_contiguous(int block, int n) {
 }
 #endif
 
+// Device scratch arena (uavac_api.hip).  reserve() makes room for `bytes` in total (synchronises the stream and
+// reallocates when it has to grow) and rewinds the arena; take() hands out 256-byte aligned pieces of it.
+int uavac_arena_reserve(uavac_ctx *ctx, size_t bytes);
+void *uavac_arena_take(uavac_ctx *ctx, size_t bytes);
+static inline size_t uavac_arena_size(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+// One small temporary: reserve + take.
+int uavac_scratch(uavac_ctx *ctx, size_t bytes, void **out);
+// Pinned staging: at least `bytes` of page-locked host memory in ctx->h_pin.
+int uavac_pin_reserve(uavac_ctx *ctx, size_t bytes);
+
 // Kernel-side view of uavac_vehicle with the per-call constants hoisted on the host.
 struct VehK {
     double g, dt, dt_outer, mass, inv_mass;
@@ -85,9 +125,18 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
                           int32_t *status);
 int uavac_launch_solve(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                        int32_t *status);
+// Optional outputs / inputs of the sampler (minsnap_sample.hip)
+struct SampleExtras {
+    const double *aabb = nullptr;    // [6] cuboid of the collision scan, with
+    int32_t *hit = nullptr;          // [B][m] hit flags
+    double *yaw_dense = nullptr;     // [rows] the yaw column on its own
+    double *jerk = nullptr;          // [rows][3]
+    double *snap = nullptr;          // [rows][3]
+    int64_t capacity_rows = -1;      // rows the trajectory buffer holds; < 0: not checked
+};
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
-                        int B, int m, double dt, double *traj, const double *aabb = nullptr, int32_t *hit = nullptr,
-                        double *yaw_dense = nullptr);
+                        int B, int m, double dt, double *traj, const SampleExtras &x);
+int uavac_launch_yaw_scan(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B, double *yaws);
 int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positions, int B, int hover, double *state,
                             int32_t *istate);
 // What the rollout needs to evaluate target rows itself instead of reading them (control_rollout.hip, POLY)

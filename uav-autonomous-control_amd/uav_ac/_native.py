@@ -15,7 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libuavac.so")
 
-OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM = 0, -1, -2, -3, -4, -5
+OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM = 0, -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 MAX_SEGMENTS = 64
 TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 26, 3, 12
 
@@ -57,6 +58,10 @@ _SIGNATURES = {
     "uavac_set_stream": (C.c_int, [_P, _P]),
     "uavac_reset_stream": (C.c_int, [_P]),
     "uavac_synchronize": (C.c_int, [_P]),
+    "uavac_device": (C.c_int, [_P]),
+    "uavac_last_rollout_kernel": (C.c_char_p, [_P]),
+    "uavac_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "uavac_take_flags": (C.c_int, [_P, _P]),
     "uavac_vehicle_default": (None, [C.POINTER(Vehicle)]),
     "uavac_minsnap_row_counts_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
     "uavac_minsnap_solve_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
@@ -64,6 +69,11 @@ _SIGNATURES = {
     "uavac_minsnap_sample_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P]),
     "uavac_minsnap_sample_yaw_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_minsnap_sample_hits_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
+    "uavac_minsnap_sample_derivs_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
+    "uavac_minsnap_plan_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P, _P,
+                                          C.c_int64, _P]),
+    "uavac_yaw_scan_dev": (C.c_int, [_P, _P, _P, C.c_int, _P]),
+    "uavac_yaw_scan": (C.c_int, [_P, _P, C.c_int64, _P]),
     "uavac_minsnap_row_counts": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
     "uavac_minsnap_solve": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_minsnap_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
@@ -93,6 +103,15 @@ _SIGNATURES = {
     "uavac_rrt_path_cost": (C.c_int, [_P, _P, C.c_int, _P]),
     "uavac_rrt_steer_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P]),
     "uavac_rrt_steer": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P]),
+    "uavac_comm_unique_id": (C.c_int, [_P, _P]),
+    "uavac_comm_init_rank": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "uavac_comm_destroy": (C.c_int, [_P, _P]),
+    "uavac_comm_abort": (C.c_int, [_P, _P]),
+    "uavac_comm_shape": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "uavac_gather_counts": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "uavac_gather_rows_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, C.c_int, _P]),
+    "uavac_comm_finish": (C.c_int, [_P, _P]),
+    "uavac_comm_loopback_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
 }
 
 _lib = None
@@ -103,8 +122,12 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            # not a fallback: build the HIP library from source (hipcc cross-compiles for gfx950), or fail loudly
+            # never a fallback: either the HIP library gets built from source on request (UAVAC_AUTOBUILD=1; hipcc
+            # cross-compiles for gfx950), or loading fails loudly with the command that builds it
             pkg = os.path.dirname(os.path.dirname(LIB_PATH))
+            if os.environ.get("UAVAC_AUTOBUILD") != "1":
+                raise UavacError(EHIP, f"{LIB_PATH} has not been built: run `make -C {pkg}` (or set UAVAC_AUTOBUILD=1 "
+                                       "to let the first import do it); there is no CPU fallback")
             import subprocess
             try:
                 subprocess.run(["make", "-C", pkg, "-j4"], check=True, capture_output=True)
@@ -126,15 +149,35 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+_live_contexts = None
+
+
+def _close_live_contexts():
+    for ref in list(_live_contexts or ()):
+        ctx = ref()
+        if ctx is not None:
+            ctx.close()
+
+
 class Context:
     """Owns one `uavac_ctx` (one HIP stream on one GPU)."""
 
     def __init__(self, device: int = -1):
+        global _live_contexts
         self._h = _P()
-        rc = lib().uavac_create(C.byref(self._h), device)
+        rc = lib().uavac_create(C.byref(self._h), -1 if device is None else int(device))
         if rc != OK:
             self._h = _P()
             raise UavacError(rc, "uavac_create failed: no usable MI355X / HIP runtime (there is no CPU fallback)")
+        # contexts are destroyed by an atexit hook registered AFTER torch's HIP runtime came up, i.e. run BEFORE its
+        # teardown -- not left to __del__ during interpreter shutdown, when the runtime may already be gone
+        import atexit
+        import weakref
+        if _live_contexts is None:
+            _live_contexts = set()
+            atexit.register(_close_live_contexts)
+        self._ref = weakref.ref(self)
+        _live_contexts.add(self._ref)
 
     def close(self):
         h = getattr(self, "_h", None)
@@ -144,6 +187,8 @@ class Context:
             except Exception:                                    # pragma: no cover
                 pass
             self._h = _P()
+        if _live_contexts is not None:
+            _live_contexts.discard(getattr(self, "_ref", None))
 
     __del__ = close
 
@@ -164,6 +209,12 @@ class Context:
 
     def synchronize(self):
         self.call("uavac_synchronize")
+
+    def set_option(self, name: str, value: int):
+        self.call("uavac_set_option", name.encode(), int(value))
+
+    def last_rollout_kernel(self) -> str:
+        return (lib().uavac_last_rollout_kernel(self._h) or b"").decode()
 
 
 def np_ptr(a: np.ndarray | None):

@@ -104,10 +104,17 @@ class Engine:
         torch = _torch()
         if not torch.cuda.is_available():
             raise nat.UavacError(nat.EHIP, "no GPU visible: the uavac engine has no CPU fallback")
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        with torch.cuda.device(self.device):
-            self.ctx = nat.Context(self.device.index)
+        dev = torch.device("cuda") if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise nat.UavacError(nat.EHIP, f"device {dev} is not a GPU: the uavac engine has no CPU fallback")
+        if dev.index is None:                                   # "cuda": the thread's current device
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        # the ctx remembers its device; every C entry point makes it current for its own duration (and restores the
+        # caller's), so an Engine for cuda:1 works while cuda:0 is torch's current device
+        self.ctx = nat.Context(self.device.index)
         self._torch = torch
+        self._comm = None
 
     # -- plumbing ---------------------------------------------------------------
     def _bind_stream(self):
@@ -120,8 +127,10 @@ class Engine:
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
 
     # -- planning ---------------------------------------------------------------
-    def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01) -> Plan:
-        """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124)."""
+    def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True) -> Plan:
+        """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124).
+        `strict`: raise UavacError(ESINGULAR) when a mission's knot system is singular (a repeated waypoint) instead of
+        returning NaN coefficients for it; with strict=False inspect `plan.status`."""
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -144,7 +153,56 @@ class Engine:
         yaw = torch.empty((total,), dtype=torch.float64, **kw)
         plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw)
         self.sample(plan)
+        if strict:
+            self.check(plan)
         return plan
+
+    def replan(self, plan: Plan):
+        """The whole chain again into plan's buffers -- times + row counts, offsets, solve, sampler + yaw column --
+        enqueued by ONE call into the C ABI (`uavac_minsnap_plan_dev`): no allocation, no sync, no Python between
+        the four launches.  The buffers keep their size: a plan that would need more rows than `plan.traj` holds is
+        refused on the device (flag 2, see `take_flags`)."""
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_plan_dev", _ptr(plan.waypoints), plan.B, plan.m, plan.velocity, plan.dt,
+                      _ptr(plan.times), _ptr(plan.seg_rows), _ptr(plan.row_offsets), _ptr(plan.coeffs), _ptr(plan.status),
+                      _ptr(plan.traj), int(plan.traj.shape[0]), _ptr(plan.yaw))
+
+    def take_flags(self):
+        """Synchronise and return-and-clear the sticky device-side flags of the `_dev` planning entry points:
+        [non-finite duration, singular system, trajectory buffer too small, mission longer than 2^31-1 rows]."""
+        fl = (C.c_int32 * 4)()
+        self._bind_stream()
+        self.ctx.call("uavac_take_flags", fl)
+        return [int(v) for v in fl]
+
+    def sample_derivatives(self, plan: Plan):
+        """Jerk and snap along the plan's rows: (N, 3) each -- `polynom(8, 3, t) @ coeffs` and `polynom(8, 4, t) @
+        coeffs`, the samples minimum_snap.py:111-112 holds in comments.  Separate arrays; plan.traj keeps its 11
+        columns (and is rewritten with the same values)."""
+        torch = self._torch
+        jerk = torch.empty((plan.total_rows, 3), dtype=torch.float64, device=self.device)
+        snap = torch.empty((plan.total_rows, 3), dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_sample_derivs_dev", _ptr(plan.coeffs), _ptr(plan.seg_rows), _ptr(plan.row_offsets),
+                      plan.B, plan.m, plan.dt, _ptr(plan.traj), _ptr(plan.yaw), _ptr(jerk), _ptr(snap))
+        return jerk, snap
+
+    def yaw_scan(self, velocities, offsets=None):
+        """Batched `MinimumSnap._calculate_yaws` (minimum_snap.py:126-136): velocities (N, 3) rows of B sequences back
+        to back, sequence b = rows offsets[b]:offsets[b+1] (default: one sequence).  -> yaws (N,) on the GPU."""
+        torch = self._torch
+        v = self._dev(velocities, torch.float64)
+        if v.dim() != 2 or v.shape[1] != 3:
+            raise ValueError(f"velocities must have shape (N, 3), got {tuple(v.shape)}")
+        n = int(v.shape[0])
+        off = self._dev([0, n] if offsets is None else offsets, torch.int64)
+        if off.dim() != 1 or off.numel() < 2:
+            raise ValueError("offsets must be a 1-D array of B+1 row indices")
+        yaws = torch.empty((n,), dtype=torch.float64, device=self.device)
+        if n:
+            self._bind_stream()
+            self.ctx.call("uavac_yaw_scan_dev", _ptr(v), _ptr(off), int(off.numel()) - 1, _ptr(yaws))
+        return yaws
 
     def plan_collision_free(self, waypoints, obstacles, velocity: float = 1.0, dt: float = 0.01,
                             max_iterations: int = 64, strict: bool = True, recheck_passes: int = 0) -> RaggedPlan:
@@ -481,15 +539,95 @@ def shard_bounds(B: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_rows(rows, dst: int = 0, group=None, max_message_bytes: int = 1 << 30):
-    """Gather ragged (n_r, C) row blocks to `dst` with point-to-point sends (one direct xGMI link per
+def gather_layout(counts, dst: int):
+    """Where every rank's block lands in the root's buffer: row offsets (world + 1,) and the peers that send.
+    Shared by the RCCL path (whose C side derives the same offsets from the same counts) and the host rehearsal."""
+    offs = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
+    return offs, [r for r in range(len(counts)) if r != dst and counts[r] > 0]
+
+
+class RcclComm:
+    """The communicator of the final gather: an ncclComm_t owned through the C ABI (`uavac_comm_*`, include/uavac.h).
+
+    Bootstrap needs one side channel for the 128-byte unique id; here it is the already initialised
+    `torch.distributed` process group (any backend), nothing else of torch takes part in the exchange."""
+
+    def __init__(self, engine: Engine, group=None, unique_id: bytes = None, world: int = None, rank: int = None):
+        torch = engine._torch
+        self.engine = engine
+        if unique_id is None:
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            box = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+                engine.ctx.call("uavac_comm_unique_id", buf)
+                box[0] = bytes(buf.raw)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            unique_id = box[0]
+        if len(unique_id) != nat.COMM_ID_BYTES:
+            raise ValueError("the RCCL unique id has 128 bytes")
+        self.world, self.rank = int(world), int(rank)
+        self._h = _P()
+        engine._bind_stream()
+        engine.ctx.call("uavac_comm_init_rank", C.create_string_buffer(unique_id, nat.COMM_ID_BYTES), self.world, self.rank,
+                        C.byref(self._h))
+
+    def counts(self, n_rows: int):
+        out = (C.c_int64 * self.world)()
+        self.engine._bind_stream()
+        self.engine.ctx.call("uavac_gather_counts", self._h, int(n_rows), out)
+        return [int(v) for v in out]
+
+    def gather_rows(self, rows, dst: int = 0):
+        """Ragged (n_r, C) f64 row blocks of all ranks -> (all_rows on dst | None, counts).  Synchronous."""
+        e, torch = self.engine, self.engine._torch
+        if not rows.is_cuda or rows.dtype != torch.float64 or rows.dim() != 2:
+            raise ValueError("rows must be a 2-D float64 GPU tensor")
+        rows = rows.contiguous()
+        counts = self.counts(rows.shape[0])
+        out = None
+        if self.rank == dst:
+            out = torch.empty((sum(counts), rows.shape[1]), dtype=torch.float64, device=e.device)
+        e._bind_stream()
+        e.ctx.call("uavac_gather_rows_dev", self._h, _ptr(rows), int(rows.shape[0]), int(rows.shape[1]),
+                   (C.c_int64 * self.world)(*counts), int(dst), _ptr(out))
+        e.ctx.call("uavac_comm_finish", self._h)
+        return out, counts
+
+    def loopback(self, src):
+        """Self-test of the transport on one GPU: src -> copy through ncclSend + ncclRecv to this very rank."""
+        e, torch = self.engine, self.engine._torch
+        src = src.contiguous()
+        dst = torch.empty_like(src)
+        e._bind_stream()
+        e.ctx.call("uavac_comm_loopback_dev", self._h, _ptr(src), _ptr(dst), int(src.numel()))
+        e.ctx.call("uavac_comm_finish", self._h)
+        return dst
+
+    def close(self, abort: bool = False):
+        if self._h.value:
+            try:
+                self.engine.ctx.call("uavac_comm_abort" if abort else "uavac_comm_destroy", self._h)
+            finally:
+                self._h = _P()
+
+
+def gather_rows(rows, dst: int = 0, group=None, max_message_bytes: int = 1 << 30, comm: "RcclComm" = None):
+    """Gather ragged (n_r, C) row blocks to `dst` with point-to-point transfers (one direct xGMI link per
     peer into the root; a ring all-gather would push 7/8 of the total through every link).
 
-    Works on CPU tensors with gloo and on GPU tensors with nccl (= RCCL).  A rank's block travels as
-    messages of at most `max_message_bytes` (whole rows), all posted in one group.  Returns (all_rows,
-    counts) on dst and (None, counts) elsewhere.
+    GPU tensors travel over RCCL behind the C ABI (`comm`: an RcclComm; `uavac_gather_rows_dev` =
+    ncclGroupStart + ncclSend / ncclRecv + ncclGroupEnd).  HOST tensors take the same layout through
+    `torch.distributed` point-to-point messages (gloo): the rehearsal path of the multi-process CPU tests, where no
+    GPU exists.  Returns (all_rows, counts) on dst and (None, counts) elsewhere.
     """
     torch = _torch()
+    if rows.is_cuda:
+        if comm is None:
+            raise ValueError("GPU rows are gathered over RCCL: pass comm=RcclComm(engine)")
+        return comm.gather_rows(rows, dst)
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
@@ -505,17 +643,16 @@ def gather_rows(rows, dst: int = 0, group=None, max_message_bytes: int = 1 << 30
     def pieces(count):
         return [(a, min(a + step, count)) for a in range(0, count, step)]
 
+    offs, senders = gather_layout(counts, dst)
     if rank == dst:
-        out = torch.empty((sum(counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-        offs = np.concatenate([[0], np.cumsum(counts)])
+        out = torch.empty((int(offs[-1]),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         out[offs[dst]:offs[dst + 1]].copy_(rows)
-        # one grouped launch: under RCCL the receives run concurrently, one per direct xGMI link into the root
         ops = [dist.P2POp(dist.irecv, out[offs[r] + a:offs[r] + b], peer(r), group)
-               for r in range(world) if r != dst for a, b in pieces(counts[r])]
+               for r in senders for a, b in pieces(counts[r])]
         for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         return out, counts
-    if counts[rank] > 0:
+    if rank in senders:
         mine = rows.contiguous()
         ops = [dist.P2POp(dist.isend, mine[a:b], peer(dst), group) for a, b in pieces(counts[rank])]
         for q in dist.batch_isend_irecv(ops):
