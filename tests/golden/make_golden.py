@@ -150,6 +150,44 @@ def gen_yaws():
     save("yaws.npz", **out)
 
 
+def gen_derivatives():
+    """Jerk and snap samples exactly as minimum_snap.py:111-112 would compute them (the two lines are comments
+    upstream): polynom(8, 3 | 4, t) @ coeffs over the sampler's own np.arange(0, T, dt) grid, with the reference's
+    polynom and the reference's coefficients."""
+    out = {}
+    cases = {"config1": CONFIG1_WAYPOINTS}
+    for i, w in enumerate(synthetic_missions(3, 12)):
+        cases[f"m12_{i}"] = w
+    for name, wp in cases.items():
+        ms = ref_plan(wp, None, 3.0, 0.01)
+        jerk, snap = [], []
+        for it in range(ms.nb_splines):
+            c = ms.coeffs[it * 8:(it + 1) * 8]
+            for t in np.arange(0.0, ms.times[it], ms.dt):
+                jerk.append(MinimumSnap.polynom(8, 3, t) @ c)
+                snap.append(MinimumSnap.polynom(8, 4, t) @ c)
+        out[name + "_wp"] = np.asarray(wp)
+        out[name + "_coeffs"] = ms.coeffs
+        out[name + "_jerk"] = np.array(jerk)
+        out[name + "_snap"] = np.array(snap)
+        assert len(jerk) == len(ms.full_trajectory)
+    save("derivatives.npz", **out)
+
+
+def gen_yaws_long():
+    """_calculate_yaws on sequences far longer than one mission (any length is legal upstream)."""
+    rng = np.random.default_rng(11)
+    out = {}
+    for name, n in (("n5000", 5000), ("n20000", 20000)):
+        ang = np.cumsum(rng.uniform(-0.9, 0.9, n))
+        v = np.stack([np.cos(ang), np.sin(ang), rng.standard_normal(n)], axis=1) * rng.uniform(0, 2, (n, 1))
+        v[rng.random(n) < 0.15] *= 1e-5
+        v[:300] *= 1e-6                                   # a long run of rows without heading first (back-fill)
+        out[name + "_vel"] = v
+        out[name + "_yaw"] = MinimumSnap._calculate_yaws(v)
+    save("yaws_long.npz", **out)
+
+
 # --------------------------------------------------------------- controller
 def random_states(rng, n):
     X = np.zeros((n, 13))
@@ -290,10 +328,8 @@ def gen_closed_loop():
 
 
 if __name__ == "__main__":
-    gen_polynom()
-    gen_fixed_missions()
-    gen_synthetic_missions()
-    gen_yaws()
-    gen_controller_io()
-    gen_open_loop()
-    gen_closed_loop()
+    all_gens = {"polynom": gen_polynom, "fixed_missions": gen_fixed_missions, "synthetic_missions": gen_synthetic_missions,
+                "yaws": gen_yaws, "derivatives": gen_derivatives, "yaws_long": gen_yaws_long,
+                "controller_io": gen_controller_io, "open_loop": gen_open_loop, "closed_loop": gen_closed_loop}
+    for name in (sys.argv[1:] or list(all_gens)):          # no arguments: everything; else only the named fixtures
+        all_gens[name]()

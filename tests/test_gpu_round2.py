@@ -1,0 +1,259 @@
+"""GPU tests of what round 2 added behind the C ABI: the RCCL gather (world-1 self-test of the very calls the 8-GPU
+gather makes), the one-call planning chain, sticky-flag handling, the stand-alone yaw scan, jerk / snap outputs, the
+device guard, the rollout's launch shapes, and the per-rank shard of BASELINE config 4 at full size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import col_err, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from uav_ac import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from uav_ac.fleet import Engine
+    return Engine("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------- RCCL behind the C ABI
+def test_rccl_world1_gather_and_loopback(eng, nat):
+    """ncclCommInitRank / ncclAllGather / ncclSend + ncclRecv through libuavac.so on one GPU: the calls of the
+    8-GPU gather with world = 1 (the root's own block) and with this rank as its own peer (loopback)."""
+    import torch
+    from uav_ac.fleet import RcclComm
+    buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+    eng.ctx.call("uavac_comm_unique_id", buf)
+    comm = RcclComm(eng, unique_id=bytes(buf.raw), world=1, rank=0)
+    try:
+        w, r = C.c_int(-1), C.c_int(-1)
+        eng.ctx.call("uavac_comm_shape", comm._h, C.byref(w), C.byref(r))
+        assert (w.value, r.value) == (1, 0)
+        assert comm.counts(12345) == [12345]
+        rows = torch.randn((70001, 11), dtype=torch.float64, device=eng.device)
+        out, counts = comm.gather_rows(rows, dst=0)
+        assert counts == [70001] and out.data_ptr() != rows.data_ptr() and torch.equal(out, rows)
+        empty, c0 = comm.gather_rows(rows[:0], dst=0)
+        assert c0 == [0] and empty.shape == (0, 11)
+        # the transport itself: 96 MB through ncclSend -> ncclRecv, bit for bit
+        src = torch.randn((12_000_000,), dtype=torch.float64, device=eng.device)
+        assert torch.equal(comm.loopback(src), src)
+        # argument checking happens before anything is enqueued
+        cnt = (C.c_int64 * 1)(5)
+        with pytest.raises(nat.UavacError) as e:
+            eng.ctx.call("uavac_gather_rows_dev", comm._h, C.c_void_p(rows.data_ptr()), 5, 11, cnt, 3, C.c_void_p(out.data_ptr()))
+        assert e.value.code == nat.EINVAL
+        with pytest.raises(nat.UavacError) as e:          # counts[rank] must be this rank's n_rows
+            eng.ctx.call("uavac_gather_rows_dev", comm._h, C.c_void_p(rows.data_ptr()), 6, 11, cnt, 0, C.c_void_p(out.data_ptr()))
+        assert e.value.code == nat.EINVAL
+        with pytest.raises(ValueError):
+            comm.gather_rows(rows.float(), dst=0)
+    finally:
+        comm.close()
+
+
+def test_gather_rows_refuses_gpu_rows_without_a_communicator(eng):
+    import torch
+    from uav_ac.fleet import gather_rows
+    with pytest.raises(ValueError):
+        gather_rows(torch.zeros((4, 11), dtype=torch.float64, device=eng.device))
+
+
+# ------------------------------------------------------------------------------------------- one-call planning chain
+def test_replan_is_bit_identical_to_the_separate_calls_and_checks_capacity(eng, nat):
+    import torch
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(300, 8)
+    plan = eng.plan(wps, 3.0, 0.01)
+    ref = {k: getattr(plan, k).clone() for k in ("times", "seg_rows", "row_offsets", "coeffs", "traj", "yaw")}
+    for k in ("times", "coeffs", "traj", "yaw"):
+        getattr(plan, k).fill_(float("nan"))
+    plan.seg_rows.zero_(); plan.row_offsets.zero_()
+    eng.replan(plan)
+    assert eng.take_flags() == [0, 0, 0, 0]
+    for k, v in ref.items():
+        assert torch.equal(getattr(plan, k), v), k
+    # a row buffer that is one row short: nothing is written, flag 2 is raised, and reading the flags clears them
+    short = plan.traj[:-1].clone()
+    short.fill_(-7.0)
+    full, plan.traj = plan.traj, short
+    eng.replan(plan)
+    assert eng.take_flags() == [0, 0, 1, 0]
+    assert bool((short == -7.0).all())
+    plan.traj = full
+    assert eng.take_flags() == [0, 0, 0, 0]
+
+
+def test_sticky_flags_do_not_leak_into_host_twins_and_plan_raises_on_singular(eng, nat):
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(4, 3)
+    bad = wps.copy()
+    bad[2, 2] = bad[2, 1]                         # a repeated waypoint: zero-length segment -> singular knot system
+    with pytest.raises(nat.UavacError) as e:
+        eng.plan(bad, 3.0, 0.01)
+    assert e.value.code == nat.ESINGULAR
+    plan = eng.plan(bad, 3.0, 0.01, strict=False)        # the device flag is now set and nobody has read it
+    assert plan.status.cpu().tolist() == [0, 0, 1, 0]
+    # a host twin on the same context with valid input must not report the stale flag
+    coeffs = np.empty((4, 24, 3)); times = np.empty((4, 3))
+    eng._bind_stream()
+    eng.ctx.call("uavac_minsnap_solve", nat.np_ptr(wps), 4, 3, 3.0, nat.np_ptr(coeffs), nat.np_ptr(times))
+    assert np.isfinite(coeffs).all()
+    with pytest.raises(nat.UavacError) as e:
+        eng.ctx.call("uavac_minsnap_solve", nat.np_ptr(bad), 4, 3, 3.0, nat.np_ptr(coeffs), nat.np_ptr(times))
+    assert e.value.code == nat.ESINGULAR
+    assert eng.take_flags() == [0, 0, 0, 0]
+
+
+# ------------------------------------------------------------------------------------------- yaw scan on its own
+def test_yaw_scan_matches_reference_on_crafted_and_long_sequences(eng):
+    from uav_ac.planning.minimum_snap import MinimumSnap
+    g = load_golden("yaws.npz")
+    for name in ("hold", "cross_pi", "none_valid", "exact_pi_steps", "leading_invalid", "random_spin"):
+        got = MinimumSnap._calculate_yaws(g[name + "_vel"])
+        assert got.shape == g[name + "_yaw"].shape
+        assert np.allclose(got, g[name + "_yaw"], rtol=0, atol=1e-12), name
+    gl = load_golden("yaws_long.npz")
+    for name in ("n5000", "n20000"):                      # far beyond the 64 samples the round-1 facade accepted
+        got = MinimumSnap._calculate_yaws(gl[name + "_vel"])
+        assert np.max(np.abs(got - gl[name + "_yaw"])) < 1e-9 * max(1.0, np.max(np.abs(gl[name + "_yaw"]))), name
+    assert MinimumSnap._calculate_yaws(np.zeros((0, 3))).shape == (0,)
+    # batched, device resident: several sequences in one launch == each on its own
+    vel = np.vstack([gl["n5000_vel"], g["random_spin_vel"], gl["n20000_vel"][:777]])
+    offs = np.cumsum([0, 5000, 400, 777])
+    y = eng.yaw_scan(vel, offs).cpu().numpy()
+    assert np.array_equal(y[:5000], MinimumSnap._calculate_yaws(gl["n5000_vel"]))
+    assert np.array_equal(y[5000:5400], MinimumSnap._calculate_yaws(g["random_spin_vel"]))
+    assert np.array_equal(y[5400:], MinimumSnap._calculate_yaws(gl["n20000_vel"][:777]))
+
+
+def test_sampler_yaw_equals_standalone_scan_of_its_own_velocities(eng):
+    from oracle import minsnap_oracle as mo
+    plan = eng.plan(mo.synthetic_missions(64, 12), 3.0, 0.01)
+    y = eng.yaw_scan(plan.traj[:, 3:6].contiguous(), plan.row_offsets)
+    import torch
+    assert torch.equal(y, plan.traj[:, 9].contiguous()) and torch.equal(y, plan.yaw)
+
+
+# ------------------------------------------------------------------------------------------- jerk / snap
+def test_jerk_and_snap_match_reference_polynom_products(eng):
+    g = load_golden("derivatives.npz")
+    import torch
+    for name, m in (("config1", 4), ("m12_0", 12), ("m12_1", 12), ("m12_2", 12)):
+        plan = eng.plan(g[name + "_wp"][None], 3.0, 0.01)
+        before = plan.traj.clone()
+        jerk, snap = eng.sample_derivatives(plan)
+        assert torch.equal(plan.traj, before)                       # the (N, 11) rows are untouched by the extra outputs
+        assert jerk.shape == (plan.total_rows, 3) == tuple(g[name + "_jerk"].shape)
+        assert col_err(jerk.cpu().numpy(), g[name + "_jerk"]) < TOL, name
+        assert col_err(snap.cpu().numpy(), g[name + "_snap"]) < TOL, name
+    # against the oracle on the device's own coefficients: rounding-level agreement
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(3, 8)
+    plan = eng.plan(wps, 2.0, 0.02)
+    jerk, snap = eng.sample_derivatives(plan)
+    for b in range(3):
+        lo, hi = int(plan.row_offsets[b]), int(plan.row_offsets[b + 1])
+        j_ref, s_ref = mo.sample_jerk_snap(plan.coeffs[b].cpu().numpy(), plan.times[b].cpu().numpy(), 0.02)
+        assert col_err(jerk[lo:hi].cpu().numpy(), j_ref) < 1e-10 and col_err(snap[lo:hi].cpu().numpy(), s_ref) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------- device guard
+def test_engine_resolves_device_and_restores_the_callers(nat):
+    import torch
+    from uav_ac.fleet import Engine
+    e = Engine("cuda")                               # no index: the current device (round-1 ADVICE: raised TypeError)
+    assert e.device.index == torch.cuda.current_device()
+    lib = nat.lib()
+    assert lib.uavac_device(e.ctx._h) == e.device.index
+    with pytest.raises(nat.UavacError):
+        Engine("cpu")
+    if torch.cuda.device_count() > 1:               # only on multi-GPU boxes: a ctx for GPU 1 while GPU 0 is current
+        from oracle import minsnap_oracle as mo
+        torch.cuda.set_device(0)
+        e1 = Engine("cuda:1")
+        plan = e1.plan(mo.synthetic_missions(8, 3), 3.0, 0.01)
+        assert plan.traj.device.index == 1 and torch.cuda.current_device() == 0
+        ref = Engine("cuda:0").plan(mo.synthetic_missions(8, 3), 3.0, 0.01)
+        assert torch.equal(plan.traj.cpu(), ref.traj.cpu())
+
+
+# ------------------------------------------------------------------------------------------- launch shapes
+def test_rollout_launch_shapes_and_aligner_do_not_change_a_bit(nat):
+    """One compute + one store wave per 64 UAVs (with or without the aligner launch) and four + four per 256 UAVs are
+    the same arithmetic: logs and final state bit-identical at the full-chip launch size."""
+    import torch
+    from uav_ac.fleet import Engine
+    from bench import missions
+    B, K = 65536, 300
+    wps = missions(B, 4, 0, B)
+    logs = []
+    for shape, align in ((1, 1), (1, 0), (4, 1)):
+        e = Engine("cuda:0")
+        e.ctx.set_option("rollout_shape", shape)
+        e.ctx.set_option("rollout_align", align)
+        plan = e.plan(wps, 3.0, 0.01)
+        fleet = e.fleet(plan)
+        slog, _ = fleet.rollout(K, state_log=True)
+        assert e.ctx.last_rollout_kernel().startswith(f"control_rollout_kernel<{shape}, {shape}, true, false, false, true>")
+        logs.append((slog, fleet.state.clone(), fleet.istate.clone()))
+        del fleet, plan
+    for other in logs[1:]:
+        assert torch.equal(other[0], logs[0][0]) and torch.equal(other[1], logs[0][1]) and torch.equal(other[2], logs[0][2])
+    with pytest.raises(nat.UavacError):
+        Engine("cuda:0").ctx.set_option("rollout_shape", 3)
+
+
+# ------------------------------------------------------------------------------------------- config 4, one rank's shard
+def test_full_size_properties_config4_rank_shard(eng):
+    """BASELINE configs[3], the share of one of 8 ranks: 32 768 UAVs, 8-segment missions, 5 000 ticks (5 launches x
+    1 000 with the state log).  Size-independent properties + spot lanes against the C oracle."""
+    import torch
+    from bench import missions
+    from oracle import c_oracle as co
+    from uav_ac.fleet import shard_bounds
+    world, rank = 8, 5
+    lo, hi = shard_bounds(262144, rank, world)
+    assert hi - lo == 32768
+    wps = missions(262144, 8, lo, hi)                    # this rank's contiguous block of the 262 144 missions
+    plan = eng.plan(wps, 3.0, 0.01)
+    fleet = eng.fleet(plan)
+    B, K, CH = 32768, 5000, 1000
+    log = torch.empty((CH, 13, B), dtype=torch.float64, device=eng.device)
+    spots = [0, 1, 9999, 20000, B - 1]
+    kept = []
+    sums = []
+    for c in range(K // CH):
+        fleet.rollout(CH, state_log=log)
+        kept.append(log[:, :, spots].clone())
+        sums.append(log.sum(dim=(1, 2)))
+    slog = torch.cat(kept).cpu().numpy()
+    nrows = (plan.row_offsets[1:] - plan.row_offsets[:-1])
+    idx = fleet.trajectory_index.long()
+    assert bool((idx == torch.clamp(torch.full_like(nrows, K // 10), max=nrows - 1)).all())
+    assert bool((fleet.istate[1] == K).all())
+    q = fleet.X[3:7]
+    finite = torch.isfinite(fleet.state).all(dim=0)
+    assert float(finite.double().mean()) == 1.0
+    assert float(((q * q).sum(dim=0) - 1).abs().max()) < 1e-9           # attitude stays unit
+    # the same flight in one launch without a log ends in the same state, bit for bit
+    f2 = eng.fleet(plan)
+    f2.rollout(K)
+    assert torch.equal(f2.state, fleet.state) and torch.equal(f2.istate, fleet.istate)
+    # spot lanes against the scalar C oracle (plan + 5 000 ticks)
+    for j, b in enumerate(spots):
+        traj, _, _ = co.plan(wps[b], 3.0, 0.01)
+        got = plan.mission(b)
+        assert got.shape == traj.shape and col_err(got, traj) < TOL
+        state, istate = co.initial_state(traj[0, 0:3])
+        s_ref, _ = co.rollout(traj, state, istate, K, log_cmd=False)
+        assert col_err(slog[:, :, j], s_ref) < TOL, b

@@ -121,9 +121,9 @@ int uavac_gather_rows_dev(uavac_ctx *ctx, void *nccl_comm, const double *rows, i
     if (n_rows > 0 && !rows) return uavac_fail(ctx, UAVAC_EINVAL, "null rows");
     const size_t re = (size_t)row_elems;
     if (rank == root) {
-        if (!out) return uavac_fail(ctx, UAVAC_EINVAL, "null out on the root");
         std::vector<size_t> off((size_t)world + 1, 0);
         for (int r = 0; r < world; ++r) off[r + 1] = off[r] + (size_t)counts[r];
+        if (!out && off[world] > 0) return uavac_fail(ctx, UAVAC_EINVAL, "null out on the root");
         if (n_rows > 0 && out + off[rank] * re != rows)            // the root's own block: a device-to-device copy
             UAVAC_HIP(ctx, hipMemcpyAsync(out + off[rank] * re, rows, (size_t)n_rows * re * 8, hipMemcpyDeviceToDevice,
                                           ctx->stream));

@@ -147,23 +147,19 @@ class MinimumSnap:
 
     @staticmethod
     def _calculate_yaws(velocities: np.ndarray) -> np.ndarray:
-        """Heading hold / unwrap / back-fill (reference :126-136) through the HIP sampler's yaw scan:
-        each sample becomes a one-row spline whose c1 is the velocity."""
+        """Heading hold / unwrap / back-fill (reference :126-136) for a velocity sequence of ANY length, through the
+        HIP yaw scan on its own (`uavac_yaw_scan`, the scan the sampler fuses)."""
         vel = nat.as_f64(velocities)
+        if vel.ndim != 2 or vel.shape[1] < 2:
+            raise IndexError("velocities must have shape (N, >= 2)")        # what velocities[:, :2] would raise upstream
         n = len(vel)
         if n == 0:
             return np.zeros(0)
-        if n > nat.MAX_SEGMENTS:
-            raise ValueError(f"_calculate_yaws facade handles up to {nat.MAX_SEGMENTS} samples per call; "
-                             "longer sequences come out of get_trajectory() / Engine.plan directly")
-        coeffs = np.zeros((1, 8 * n, 3))
-        coeffs[0, 1::8, :] = vel
-        times = np.full((1, n), 0.5)
-        offs = np.array([0, n], dtype=np.int64)
-        traj = np.empty((n, nat.TRAJ_COLS))
-        ctx().call("uavac_minsnap_sample", nat.np_ptr(coeffs), nat.np_ptr(times), 1, n, 1.0, nat.np_ptr(offs),
-                   nat.np_ptr(traj))
-        return traj[:, 9].copy()
+        v3 = np.zeros((n, 3))
+        v3[:, :2] = vel[:, :2]
+        yaws = np.empty(n)
+        ctx().call("uavac_yaw_scan", nat.np_ptr(v3), n, nat.np_ptr(yaws))
+        return yaws
 
     @staticmethod
     def is_collision_cuboid(x: float, y: float, z: float, cuboid_params: np.ndarray) -> bool:
