@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UAVAC_VERSION 100 /* 0.1.0 */
+#define UAVAC_VERSION 200 /* 0.2.0: uavac_vehicle grew the ground-plane fields, istate has 4 rows */
 
 #define UAVAC_OK 0
 #define UAVAC_EINVAL (-1)    /* bad shape / size / null pointer                    */
@@ -42,7 +42,7 @@ extern "C" {
 #define UAVAC_MAX_SEGMENTS 64   /* m, segments per mission                          */
 #define UAVAC_TRAJ_COLS 11      /* x y z vx vy vz ax ay az yaw spline_id: minimum_snap.py:122-123 */
 #define UAVAC_STATE_ROWS 26     /* see uavac_control_* below                        */
-#define UAVAC_ISTATE_ROWS 3
+#define UAVAC_ISTATE_ROWS 4
 #define UAVAC_CMD_COLS 12
 
 typedef struct uavac_ctx uavac_ctx;
@@ -65,8 +65,24 @@ typedef struct uavac_vehicle {
     double kp_xy, kd_xy, kp_z, kd_z, ki_z;                /* quad.py:65-67 */
     double kp_roll, kp_pitch, kp_yaw, kp_p, kp_q, kp_r;   /* quad.py:68-73 */
     int32_t inner_per_outer;            /* config.ini:2 `frequency`  */
-    int32_t reserved;
+    int32_t ground;                     /* 0: free flight (default).  1: a horizontal ground plane the body can rest on
+                                         * and take off from -- the on-ground start of the reference's scene
+                                         * (lab_course.xml:34,98: plane at z = 0, body box of half height 0.02 m
+                                         * starting 1 mm above it).  BUILD-DEFINED contact, not MuJoCo's solver: a
+                                         * normal acceleration toward the critically damped reference
+                                         * -2 vz / tc - r / tc^2 (r = penetration of the body's lowest point) whenever
+                                         * that pushes up harder than free flight does; no friction, no contact
+                                         * torque.  Contact FORCES are therefore not comparable with MuJoCo's. */
+    double ground_z;                    /* NED z of the plane (0 = the reference scene)                      */
+    double ground_clearance;            /* body centre above its lowest point (half height of geom "body") */
+    double ground_timeconst;            /* tc: MuJoCo's default solref time constant, 0.02 s               */
 } uavac_vehicle;
+/* Ground bookkeeping bits in istate row 3 (only touched when V->ground != 0), after
+ * MujocoSimulation._record_collisions (mujoco_sim.py:220-230): */
+#define UAVAC_GROUND_IN_CONTACT 1     /* the body touches the plane after this tick (`has_collision`)      */
+#define UAVAC_GROUND_TAKEN_OFF 2      /* sticky: height >= UAVAC_TAKEOFF_HEIGHT has been reached            */
+#define UAVAC_GROUND_HIT_AFTER_TAKEOFF 4 /* sticky: contact after take-off (`collision_detected`)            */
+#define UAVAC_TAKEOFF_HEIGHT 0.1      /* TAKEOFF_HEIGHT, mujoco_sim.py:17                                   */
 
 /* ---- context ------------------------------------------------------------------ */
 int uavac_version(void);
@@ -87,12 +103,11 @@ int uavac_device(const uavac_ctx *ctx);
  * plan-fed> of the rollout kernel the ctx launched last ("" before the first): what a profile of
  * the same call will show.  Diagnostics for benchmarks; the string lives in the ctx. */
 const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
-/* Tuning knobs; results never depend on them (tested bit for bit).  "rollout_shape": workgroup
- * shape of rollout launches that write a log -- 1 = one compute + one store wave per 64 UAVs,
- * 4 = four + four per 256 UAVs for full-chip launches (65 536 columns).  "rollout_align": 1 = precede
- * a shape-1 logged launch by an empty kernel of the same workgroup shape, which makes the hardware
- * place one compute and one store wave on every SIMD whatever ran before.
- * Defaults from the environment (UAVAC_ROLLOUT_SHAPE, UAVAC_ROLLOUT_ALIGN) at uavac_create. */
+/* Tuning knobs; results never depend on them (tested bit for bit).  "rollout_align": 1 (default) =
+ * precede a rollout launch that writes a log by an empty kernel of the same workgroup shape (one
+ * compute + one store wave), which makes the hardware place one wave of each kind on every SIMD
+ * whatever ran before; 0 = do not.  Default from the environment
+ * (UAVAC_ROLLOUT_ALIGN) at uavac_create. */
 int uavac_set_option(uavac_ctx *ctx, const char *name, int value);
 /* The _dev planning entry points report data-dependent failures through sticky device-side flags
  * instead of synchronising: flags[0] non-finite segment duration, flags[1] singular knot system,
@@ -188,7 +203,8 @@ int uavac_minsnap_sample(uavac_ctx *ctx, const double *coeffs, const double *tim
  *                       rows 13-16 omega, rows 17-20 omega_command               (quad.py:83-86)
  *                       row  21    altitude integral error                       (controller.py:20)
  *                       row  22    thrust_cmd, rows 23-25 pqr_cmd                (main.py:26-27)
- *   istate [3][B]  i32: trajectory_index, inner_step (main.py:24-25), collided (sticky flag)
+ *   istate [4][B]  i32: trajectory_index, inner_step (main.py:24-25), collided (sticky obstacle flag),
+ *                       ground bookkeeping bits (UAVAC_GROUND_*; stays 0 in free flight)
  *   traj / row_offsets: as produced by uavac_minsnap_sample (UAV b follows mission b).
  */
 /* X = [position, identity attitude, rest]; rotors at hover speed if hover != 0, else 0;

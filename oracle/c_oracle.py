@@ -20,7 +20,8 @@ class Vehicle(C.Structure):
                    "arm", "kf", "kappa", "min_thrust", "max_thrust", "tau_rise", "tau_fall",
                    "max_ascent", "max_descent", "max_speed_xy", "max_horiz_accel", "max_tilt",
                    "kp_xy", "kd_xy", "kp_z", "kd_z", "ki_z", "kp_roll", "kp_pitch", "kp_yaw",
-                   "kp_p", "kp_q", "kp_r")] + [("inner_per_outer", C.c_int32), ("reserved", C.c_int32)]
+                   "kp_p", "kp_q", "kp_r")] + [("inner_per_outer", C.c_int32), ("ground", C.c_int32)] + \
+               [(n, C.c_double) for n in ("ground_z", "ground_clearance", "ground_timeconst")]
 
     @classmethod
     def default(cls):
@@ -32,7 +33,7 @@ class Vehicle(C.Structure):
                 v.inertia[:] = p.inertia
             elif n == "dt_outer":
                 v.dt_outer = p.dt_outer
-            elif n != "reserved":
+            else:
                 setattr(v, n, getattr(p, n))
         return v
 
@@ -98,11 +99,11 @@ def initial_state(position, V: Vehicle | None = None, hover: bool = True):
     state[3] = 1.0
     if hover:
         state[13:21] = np.sqrt(V.mass * V.g / (4 * V.kf))
-    return state, np.zeros(3, dtype=np.int32)
+    return state, np.zeros(4, dtype=np.int32)
 
 
 def rollout(traj, state, istate, K: int, V: Vehicle | None = None, log_state=True, log_cmd=True, aabbs=None):
-    """K ticks in place on (state[26], istate[3]) -> (state_log (K,13) | None, cmd_log (K,12) | None)."""
+    """K ticks in place on (state[26], istate[4]) -> (state_log (K,13) | None, cmd_log (K,12) | None)."""
     V = V or Vehicle.default()
     traj = np.ascontiguousarray(traj, dtype=np.float64)
     slog = np.empty((K, 13)) if log_state else None

@@ -56,6 +56,11 @@ class Vehicle:
     max_horiz_accel: float = 12.0
     max_tilt: float = 0.7
     inner_per_outer: int = 10
+    # ground plane: 0 = free flight.  BUILD-DEFINED contact law, see dynamics_step
+    ground: int = 0
+    ground_z: float = 0.0            # NED z of the plane (lab_course.xml:34)
+    ground_clearance: float = 0.02   # half height of the body box (lab_course.xml:101)
+    ground_timeconst: float = 0.02   # MuJoCo's default solref time constant
     # gains: quad.py:42-73
     kp_xy: float = field(init=False)
     kd_xy: float = field(init=False)
@@ -263,6 +268,10 @@ def rotor_wrench(V: Vehicle, omega):
     return T, np.array([tx, ty, tz])
 
 
+TAKEOFF_HEIGHT = 0.1                                                  # mujoco_sim.py:17
+GROUND_IN_CONTACT, GROUND_TAKEN_OFF, GROUND_HIT_AFTER_TAKEOFF = 1, 2, 4
+
+
 def dynamics_step(u: UAV) -> None:
     """Semi-implicit Euler free-body step, NED world / FRD body.
 
@@ -278,6 +287,16 @@ def dynamics_step(u: UAV) -> None:
     acc = np.array([0.0, 0.0, V.g]) - (T / V.mass) * R[:, 2]
     wdot = (tau - np.cross(w, I * w)) / I
     v_new = u.X[7:10] + dt * acc
+    if V.ground:
+        # BUILD-DEFINED ground contact (MuJoCo's soft-constraint solver cannot run here): while the body's lowest point
+        # is below the plane, the vertical velocity update may not exceed the critically damped reference
+        # vz + dt (-b vz - k r), b = 2/tc, k = 1/tc^2; the plane only pushes; no friction, no contact torque
+        r = u.X[2] - (V.ground_z - V.ground_clearance)
+        if r > 0.0:
+            tc = V.ground_timeconst
+            vz_ref = u.X[9] + dt * -(2.0 / tc * u.X[9] + r / (tc * tc))
+            if vz_ref < v_new[2]:
+                v_new[2] = vz_ref
     w_new = w + dt * wdot
     p_new = u.X[0:3] + dt * v_new
     q = u.X[3:7]
@@ -297,6 +316,15 @@ def dynamics_step(u: UAV) -> None:
     u.X[3:7] = q
     u.X[7:10] = v_new
     u.X[10:13] = w_new
+    if V.ground:        # bookkeeping of MujocoSimulation._record_collisions (mujoco_sim.py:220-230)
+        bits = getattr(u, "ground_bits", 0)
+        if V.ground_z - p_new[2] >= TAKEOFF_HEIGHT:
+            bits |= GROUND_TAKEN_OFF
+        touching = p_new[2] - (V.ground_z - V.ground_clearance) > 0.0
+        bits = (bits | GROUND_IN_CONTACT) if touching else (bits & ~GROUND_IN_CONTACT)
+        if touching and bits & GROUND_TAKEN_OFF:
+            bits |= GROUND_HIT_AFTER_TAKEOFF
+        u.ground_bits = bits
 
 
 def in_any_aabb(p, aabbs) -> bool:

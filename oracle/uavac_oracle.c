@@ -186,7 +186,8 @@ typedef struct {
     double g, dt, dt_outer, mass, I[3], arm, kf, kappa, min_thrust, max_thrust, tau_rise, tau_fall;
     double max_ascent, max_descent, max_speed_xy, max_horiz_accel, max_tilt;
     double kp_xy, kd_xy, kp_z, kd_z, ki_z, kp_roll, kp_pitch, kp_yaw, kp_p, kp_q, kp_r;
-    int32_t F, reserved;
+    int32_t F, ground;
+    double ground_z, ground_clearance, ground_timeconst;
 } oracle_vehicle;   /* same field order as uavac_vehicle so tests can share one ctypes struct */
 
 static double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -205,7 +206,7 @@ static void quat_to_rot(const double *q, double R[3][3]) { /* quad.py:133-155 */
 
 typedef struct {
     double X[13], omega[4], omega_cmd[4], integ, thrust, pqr[3];
-    int32_t idx, inner, collided;
+    int32_t idx, inner, collided, gbits;
 } uav_t;
 
 static void controller_tick(const oracle_vehicle *V, uav_t *u, const double *traj, int64_t nrows) {
@@ -287,8 +288,18 @@ static void dynamics_step(const oracle_vehicle *V, uav_t *u) {
     double cr[3] = {w[1] * Iw[2] - w[2] * Iw[1], w[2] * Iw[0] - w[0] * Iw[2], w[0] * Iw[1] - w[1] * Iw[0]};
     double acc[3] = {-(T / V->mass) * R[0][2], -(T / V->mass) * R[1][2], V->g - (T / V->mass) * R[2][2]};
     double wn2 = 0.0;
+    /* BUILD-DEFINED ground contact (MuJoCo's soft-constraint solver cannot run here): while the body's
+     * lowest point is below the plane, the vertical velocity update may not exceed the critically damped reference
+     * vz + dt (-b vz - k r), b = 2/tc, k = 1/tc^2; the plane only pushes; no friction, no contact torque. */
+    double vz_ref = 0.0;
+    int touching = 0;
+    if (V->ground) {
+        double r = u->X[2] - (V->ground_z - V->ground_clearance), tc = V->ground_timeconst;
+        if (r > 0.0) { touching = 1; vz_ref = u->X[9] + dt * -(2.0 / tc * u->X[9] + r / (tc * tc)); }
+    }
     for (int i = 0; i < 3; ++i) {
         u->X[7 + i] += dt * acc[i];
+        if (i == 2 && touching && vz_ref < u->X[9]) u->X[9] = vz_ref;
         w[i] += dt * ((tau[i] - cr[i]) / V->I[i]);
         u->X[i] += dt * u->X[7 + i];
         wn2 += w[i] * w[i];
@@ -304,9 +315,15 @@ static void dynamics_step(const oracle_vehicle *V, uav_t *u) {
     }
     double nn = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
     for (int i = 0; i < 4; ++i) q[i] = nq[i] / nn;
+    if (V->ground) {                                  /* MujocoSimulation._record_collisions, mujoco_sim.py:220-230 */
+        if (V->ground_z - u->X[2] >= 0.1) u->gbits |= 2;                           /* TAKEOFF_HEIGHT reached (sticky) */
+        int now = u->X[2] - (V->ground_z - V->ground_clearance) > 0.0;
+        u->gbits = now ? (u->gbits | 1) : (u->gbits & ~1);
+        if (now && (u->gbits & 2)) u->gbits |= 4;                                  /* contact after take-off (sticky) */
+    }
 }
 
-/* state [26] / istate [3] in the row order of include/uavac.h; logs [K][13] and [K][12] (or NULL) */
+/* state [26] / istate [4] in the row order of include/uavac.h; logs [K][13] and [K][12] (or NULL) */
 void oracle_rollout(const oracle_vehicle *V, const double *traj, int64_t nrows, double *state, int32_t *istate,
                     int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs) {
     uav_t u;
@@ -315,7 +332,7 @@ void oracle_rollout(const oracle_vehicle *V, const double *traj, int64_t nrows, 
     memcpy(u.omega_cmd, state + 17, 4 * sizeof(double));
     u.integ = state[21]; u.thrust = state[22];
     memcpy(u.pqr, state + 23, 3 * sizeof(double));
-    u.idx = istate[0]; u.inner = istate[1]; u.collided = istate[2];
+    u.idx = istate[0]; u.inner = istate[1]; u.collided = istate[2]; u.gbits = istate[3];
     for (int k = 0; k < K; ++k) {
         controller_tick(V, &u, traj, nrows);
         if (cmd_log) {
@@ -335,7 +352,7 @@ void oracle_rollout(const oracle_vehicle *V, const double *traj, int64_t nrows, 
     memcpy(state + 17, u.omega_cmd, 4 * sizeof(double));
     state[21] = u.integ; state[22] = u.thrust;
     memcpy(state + 23, u.pqr, 3 * sizeof(double));
-    istate[0] = u.idx; istate[1] = u.inner; istate[2] = u.collided;
+    istate[0] = u.idx; istate[1] = u.inner; istate[2] = u.collided; istate[3] = u.gbits;
 }
 
 /* ------------------------------------------------------------------ all-core timing leg (bench.py cpu_baseline)
@@ -374,7 +391,7 @@ static void *bench_worker(void *p) {
         if (rows > cap) { free(traj); cap = rows + rows / 4; traj = (double *)malloc(sizeof(double) * 11 * (size_t)cap); }
         oracle_sample(coeffs, times, m, a->dt, traj);
         double state[26] = {0};
-        int32_t istate[3] = {0, 0, 0};
+        int32_t istate[4] = {0, 0, 0, 0};
         state[0] = traj[0]; state[1] = traj[1]; state[2] = traj[2]; state[3] = 1.0;
         const double hover = sqrt(a->V->mass * a->V->g / (4.0 * a->V->kf));
         for (int r = 13; r < 21; ++r) state[r] = hover;

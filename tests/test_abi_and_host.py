@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uavac.h but not exported"
     assert sorted(nat.exported_symbols()) == declared       # the ctypes table covers the header exactly
-    assert lib.uavac_version() == 100
+    assert lib.uavac_version() == nat.VERSION == 200
 
 
 def test_vehicle_struct_layout_and_defaults():
@@ -43,6 +43,8 @@ def test_vehicle_struct_layout_and_defaults():
     assert (V.g, V.dt, V.mass, V.kappa, V.inner_per_outer) == (9.81, 0.001, 0.5, 0.016, 10)
     assert list(V.inertia) == [0.0023, 0.0023, 0.0046]
     assert V.kp_z == 1 / 0.2 ** 2 and V.kp_r == 1 / 0.09     # quad.py:53-73
+    # free flight by default; the reference scene's plane / body box / MuJoCo's default solref when switched on
+    assert (V.ground, V.ground_z, V.ground_clearance, V.ground_timeconst) == (0, 0.0, 0.02, 0.02)
 
 
 def test_no_cpu_fallback_without_gpu():

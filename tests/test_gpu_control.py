@@ -175,7 +175,7 @@ def test_reference_known_answers_through_probes(nat, ctx):
 def _single_uav_rollout(nat, ctx, traj, X0, K, omega0=None, aabbs=None):
     """B = 1 through the host-pointer twin of the rollout."""
     V = nat.Vehicle.default()
-    state = np.zeros((26, 1)); istate = np.zeros((3, 1), dtype=np.int32)
+    state = np.zeros((26, 1)); istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
     ctx.call("uavac_state_init", C.byref(V), nat.np_ptr(nat.as_f64(X0[None, 0:3])), 1, 1, nat.np_ptr(state), nat.np_ptr(istate))
     state[0:13, 0] = X0
     if omega0 is not None:
@@ -272,7 +272,7 @@ def test_hover_and_free_fall_invariants(nat, ctx):
     assert np.allclose(slog[-1, 0:3], [1.0, 7.0, -1.0], atol=1e-6) and np.allclose(slog[-1, 7:10], 0, atol=1e-6)
     # free fall: empty trajectory (no outer update), rotors off, commands zero -> thrust floor only
     state = np.zeros((26, 1)); state[3] = 1.0; state[2] = -10.0
-    istate = np.zeros((3, 1), dtype=np.int32)
+    istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
     offs = np.zeros(2, dtype=np.int64)
     slog = np.empty((10, 13, 1))
     ctx.call("uavac_control_rollout", C.byref(V), nat.np_ptr(np.zeros((1, 11))), nat.np_ptr(offs), nat.np_ptr(state),

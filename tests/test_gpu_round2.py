@@ -187,30 +187,115 @@ def test_engine_resolves_device_and_restores_the_callers(nat):
         assert torch.equal(plan.traj.cpu(), ref.traj.cpu())
 
 
-# ------------------------------------------------------------------------------------------- launch shapes
-def test_rollout_launch_shapes_and_aligner_do_not_change_a_bit(nat):
-    """One compute + one store wave per 64 UAVs (with or without the aligner launch) and four + four per 256 UAVs are
-    the same arithmetic: logs and final state bit-identical at the full-chip launch size."""
+# ------------------------------------------------------------------------------------------- aligner launch
+def test_rollout_aligner_launch_does_not_change_a_bit(nat):
+    """The empty 2-wave kernel in front of a logged rollout launch only changes where the hardware puts the waves:
+    logs and final state are bit-identical with and without it."""
     import torch
     from uav_ac.fleet import Engine
     from bench import missions
     B, K = 65536, 300
     wps = missions(B, 4, 0, B)
     logs = []
-    for shape, align in ((1, 1), (1, 0), (4, 1)):
+    for align in (1, 0):
         e = Engine("cuda:0")
-        e.ctx.set_option("rollout_shape", shape)
         e.ctx.set_option("rollout_align", align)
         plan = e.plan(wps, 3.0, 0.01)
         fleet = e.fleet(plan)
         slog, _ = fleet.rollout(K, state_log=True)
-        assert e.ctx.last_rollout_kernel().startswith(f"control_rollout_kernel<{shape}, {shape}, true, false, false, true>")
+        assert e.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, true, false>"
         logs.append((slog, fleet.state.clone(), fleet.istate.clone()))
         del fleet, plan
-    for other in logs[1:]:
-        assert torch.equal(other[0], logs[0][0]) and torch.equal(other[1], logs[0][1]) and torch.equal(other[2], logs[0][2])
+    assert torch.equal(logs[1][0], logs[0][0]) and torch.equal(logs[1][1], logs[0][1]) and torch.equal(logs[1][2], logs[0][2])
     with pytest.raises(nat.UavacError):
-        Engine("cuda:0").ctx.set_option("rollout_shape", 3)
+        Engine("cuda:0").ctx.set_option("no_such_option", 1)
+
+
+# ------------------------------------------------------------------------------------------- N3: ground plane
+def test_ground_takeoff_matches_oracle_and_free_flight_is_untouched(eng, nat):
+    """The lab mission from the reference's true start (on the ground, rotors stopped) with the build-defined ground
+    contact: HIP rollout == C oracle (1e-9 over the take-off), bookkeeping bits equal; and with the plane out of reach
+    the ground-enabled kernel reproduces the free-flight kernel bit for bit."""
+    import torch
+    from oracle import c_oracle as cc
+    from oracle import minsnap_oracle as mo
+    g = load_golden("fixed_missions.npz")
+    traj = mo.mission_trajectory(g["lab_wp"], None, 2.0, 0.01)
+    K = 6000
+    V = nat.Vehicle.default()
+    V.ground = 1
+    rows = torch.as_tensor(traj, device=eng.device)
+    offs = torch.tensor([0, len(traj)], dtype=torch.int64, device=eng.device)
+    P = lambda t: C.c_void_p(t.data_ptr())          # noqa: E731
+    pos = torch.as_tensor(traj[0:1, 0:3].copy(), device=eng.device)
+    state = torch.empty((nat.STATE_ROWS, 1), dtype=torch.float64, device=eng.device)
+    istate = torch.empty((nat.ISTATE_ROWS, 1), dtype=torch.int32, device=eng.device)
+    log = torch.empty((K, 13, 1), dtype=torch.float64, device=eng.device)
+    eng._bind_stream()
+    eng.ctx.call("uavac_state_init_dev", C.byref(V), P(pos), 1, 0, P(state), P(istate))
+    eng.ctx.call("uavac_control_rollout_dev", C.byref(V), P(rows), P(offs), P(state), P(istate), 1, K, P(log), None, None, 0)
+    assert eng.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, false, true>"
+    Vc = cc.Vehicle.default()
+    Vc.ground = 1
+    s0, i0 = cc.initial_state(traj[0, 0:3], Vc, hover=False)
+    s_ref, _ = cc.rollout(traj, s0, i0, K, Vc)
+    got = log[:, :, 0].cpu().numpy()
+    assert col_err(got, s_ref) < 1e-9
+    assert istate[:, 0].cpu().tolist() == i0.tolist() and i0[3] == nat.GROUND_TAKEN_OFF
+    assert got[:, 2].max() > -0.0205 and got[-1, 2] < -1.0          # touched down while the rotors spun up, then left
+    # plane far below: the ground-enabled kernel must be the free-flight kernel, bit for bit
+    wps = mo.synthetic_missions(256, 4)
+    plan = eng.plan(wps, 3.0, 0.01)
+    Vg = nat.Vehicle.default()
+    Vg.ground, Vg.ground_z = 1, 1000.0
+    a, b = eng.fleet(plan), eng.fleet(plan, vehicle=Vg)
+    la, _ = a.rollout(700, state_log=True)
+    lb, _ = b.rollout(700, state_log=True)
+    assert torch.equal(la, lb) and torch.equal(a.state, b.state) and torch.equal(a.istate[:3], b.istate[:3])
+    assert bool((b.istate[3] == nat.GROUND_TAKEN_OFF).all()) and bool((a.istate[3] == 0).all())
+
+
+def test_scene_simulation_ground_invariants_of_the_reference_tests():
+    """tests/unit/simulation/test_mujoco_sim.py:123-174 against the scene-reading simulation (HIP dynamics step)."""
+    from uav_ac.simulation.mujoco_sim import MujocoSimulation
+    start = np.array([1.0, 7.0, -0.021])
+    sim = MujocoSimulation()
+    assert sim.has_collision is False and sim.ground_z == 0.0 and sim.ground_clearance == 0.02
+    for _ in range(50):                                                    # :123-131
+        sim.step()
+    assert sim.has_collision is True and sim.collision_detected is False
+    sim = MujocoSimulation()                                               # :150-160
+    z0 = sim.quad.z
+    for _ in range(20):
+        sim.step()
+    assert sim.quad.z > z0 and sim.quad.z_vel > 0.0
+    sim = MujocoSimulation()                                               # :163-174
+    q = sim.quad
+    q.omega[:] = np.sqrt(q.m * q.g / (4 * q.kf))
+    for _ in range(100):
+        sim.step()
+    assert np.allclose(q.position, start, atol=1e-6) and np.allclose(q.velocity, 0.0, atol=1e-6)
+    sim = MujocoSimulation()                                               # :134-147
+    sim.quad.X[2] = -0.2
+    sim.step()
+    sim.quad.X[2] = -0.019
+    sim.quad.X[7:13] = 0.0
+    sim.step()
+    assert sim.collision_detected is True
+
+
+def test_lab_mission_from_the_ground_meets_reference_integration_bounds():
+    """tests/integration/test_mujoco_trajectory_tracking.py:34-36 from the reference's true start state: final distance
+    and mean tracking error < 0.5 m, no collision (ground contact before take-off does not count, as upstream)."""
+    from uav_ac.main import fly_mission
+    from uav_ac.simulation.mujoco_sim import DEFAULT_SCENE_PATH
+    from uav_ac import _native as nat
+    out = fly_mission(DEFAULT_SCENE_PATH, velocity=2.0, frequency=10, settle_ticks=0)
+    assert out["distance_to_goal"] < 0.5 and out["mean_tracking_error"] < 0.5 and out["collision_detected"] is False
+    assert out["ground_bits"] == nat.GROUND_TAKEN_OFF
+    assert out["states"][:, 2].max() > -0.0205                           # it really stood on the plane first
+    free = fly_mission(DEFAULT_SCENE_PATH, velocity=2.0, frequency=10, settle_ticks=0, ground=False)
+    assert free["distance_to_goal"] < 0.5 and free["ground_bits"] == 0
 
 
 # ------------------------------------------------------------------------------------------- config 4, one rank's shard

@@ -209,3 +209,68 @@ def test_closed_loop_meets_reference_integration_bounds():
     n = min(len(traj), len(s))
     err = np.linalg.norm(s[:n, 0:3] - traj[:n, 0:3], axis=1)
     assert err.mean() < 0.5 and np.linalg.norm(s[-1, 0:3] - traj[-1, 0:3]) < 0.5
+
+
+# ----------------------------------------------------------------------------- N3: ground plane (build-defined contact)
+def _ground_vehicle():
+    V = co.Vehicle()
+    V.ground, V.ground_z, V.ground_clearance, V.ground_timeconst = 1, 0.0, 0.02, 0.02
+    return V
+
+
+def test_ground_start_invariants_of_the_reference_tests():
+    """tests/unit/simulation/test_mujoco_sim.py:123-174 restated on the oracle with the build-defined ground: stopped
+    rotors -> the vehicle sinks (z grows, z' > 0 after 20 steps), rests ON the plane in contact without a collision being
+    recorded (before take-off); hover speed from the start state -> position and velocity stay within 1e-6 for 100 steps;
+    ground contact after having been above TAKEOFF_HEIGHT is recorded."""
+    start = np.array([1.0, 7.0, -0.021])
+    u = co.UAV(_ground_vehicle(), position=start, hover=False)
+    for _ in range(20):
+        co.dynamics_step(u)
+    assert u.X[2] > start[2] and u.X[9] > 0.0                         # :150-160 (gravity sign; NED z grows downwards)
+    for _ in range(30):
+        co.dynamics_step(u)
+    assert u.ground_bits & co.GROUND_IN_CONTACT                          # :123-131 has_collision is True ...
+    assert not u.ground_bits & co.GROUND_HIT_AFTER_TAKEOFF               # ... collision_detected is False
+    for _ in range(3000):
+        co.dynamics_step(u)
+    assert abs(u.X[2] - (-0.02)) < 1e-4 and abs(u.X[9]) < 1e-6          # comes to rest on the plane, does not sink in
+    assert np.allclose(u.X[[0, 1]], start[:2]) and np.allclose(u.X[3:7], [1, 0, 0, 0])
+
+    h = co.UAV(_ground_vehicle(), position=start, hover=True)            # :163-174
+    for _ in range(100):
+        co.dynamics_step(h)
+    assert np.allclose(h.X[0:3], start, atol=1e-6) and np.allclose(h.X[7:10], 0.0, atol=1e-6)
+    assert h.ground_bits == 0
+
+    t = co.UAV(_ground_vehicle(), position=(1.0, 7.0, -0.2), hover=False)  # :134-147
+    co.dynamics_step(t)
+    assert t.ground_bits == co.GROUND_TAKEN_OFF
+    t.X[2], t.X[7:10] = -0.019, 0.0
+    co.dynamics_step(t)
+    assert t.ground_bits & co.GROUND_HIT_AFTER_TAKEOFF
+
+
+def test_ground_is_inert_in_free_flight_and_c_oracle_agrees():
+    """Away from the plane the ground-enabled step is the free-flight step bit for bit; the C oracle follows the Python
+    oracle through a take-off from the ground (lab course, reference's true start) to rounding."""
+    from oracle import c_oracle as cc
+    from oracle import minsnap_oracle as mo
+    g = load_golden("fixed_missions.npz")
+    traj = mo.mission_trajectory(g["lab_wp"], None, 2.0, 0.01)
+    a, b = co.UAV(co.Vehicle(), position=(0, 0, -5.0)), co.UAV(_ground_vehicle(), position=(0, 0, -5.0))
+    a.omega[:] = b.omega[:] = [2.0, 1.2, 1.6, 1.1]
+    for _ in range(200):
+        co.dynamics_step(a); co.dynamics_step(b)
+    assert np.array_equal(a.X, b.X)
+    K = 4000
+    u = co.UAV(_ground_vehicle(), position=traj[0, 0:3], hover=False)
+    s_py, _ = co.rollout(u, traj, K)
+    Vc = cc.Vehicle.default()
+    Vc.ground = 1
+    state, istate = cc.initial_state(traj[0, 0:3], Vc, hover=False)
+    s_c, _ = cc.rollout(traj, state, istate, K, Vc)
+    assert col_err(s_c, s_py) < 1e-9
+    assert istate[3] == u.ground_bits == co.GROUND_TAKEN_OFF            # took off, never touched the ground again
+    assert s_py[:, 2].max() > -0.0205                                    # it did touch down while the rotors spun up
+    assert s_py[-1, 2] < -1.0

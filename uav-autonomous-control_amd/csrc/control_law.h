@@ -183,6 +183,15 @@ __device__ __forceinline__ void motors(const VehK &V, const double f[4], double 
 //   v' = g e3 - (T/m) R e3 ; w' = I^-1 (tau - w x I w) ; v += dt v' ; w += dt w' ; p += dt v_new ;
 //   q <- normalise(q (x) exp(dt w_new))
 // inv_n2 = 1/|q|^2 of the incoming attitude (exactly 1 when this function produced it).
+//
+// GROUND (uavac_vehicle.ground): a horizontal plane at z = V.ground_z the body rests on and takes off from
+// (lab_course.xml:34,98-101; the reference starts on the ground with stopped rotors, test_mujoco_sim.py:150-174).  MuJoCo
+// resolves that contact with its soft-constraint solver, which cannot run here; this is a BUILD-DEFINED stand-in of the
+// same character: while the body's lowest point is below the plane (r = pz - ground_zc > 0), the vertical velocity update
+// may not exceed the critically damped reference  vz + dt (-b vz - k r)  (b = 2/tc, k = 1/tc^2, tc = MuJoCo's default
+// solref time constant) -- the plane only pushes, there is no friction and no contact torque.  Out of contact the
+// arithmetic is the free-flight one, bit for bit.
+template <bool GROUND = false>
 __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4], double &px, double &py,
                                                double &pz, double &q0, double &q1, double &q2, double &q3,
                                                double &vx, double &vy, double &vz, double &wp, double &wq,
@@ -201,7 +210,14 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
         const double tm = T * V.inv_mass * V.dt;
         vx = fma(-tm, bzx, vx);
         vy = fma(-tm, bzy, vy);
-        vz = fma(V.dt, V.g, fma(-tm, bzz, vz));
+        const double vz_free = fma(V.dt, V.g, fma(-tm, bzz, vz));
+        if (GROUND) {
+            const double r = pz - V.ground_zc;
+            const double vz_ref = fma(V.dt, -fma(V.ground_b, vz, V.ground_k * r), vz);
+            vz = (r > 0.0 && vz_ref < vz_free) ? vz_ref : vz_free;
+        } else {
+            vz = vz_free;
+        }
     }
     {
         const double Jx = V.I[0] * wp, Jy = V.I[1] * wq, Jz = V.I[2] * wr;
@@ -237,6 +253,16 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
     double inv = fma(e, fma(e, 0.375, -0.5), 1.0);
     if (fabs(e) > 1.0e-6) inv = fast_rsqrt(e + 1.0);
     q0 = n0 * inv; q1 = n1 * inv; q2 = n2 * inv; q3 = n3 * inv;
+}
+
+// Ground bookkeeping after a tick (MujocoSimulation._record_collisions, mujoco_sim.py:220-230): take-off is reached at
+// TAKEOFF_HEIGHT above the plane; touching the plane before that is the start, touching it afterwards is a collision.
+__device__ __forceinline__ int ground_bits(const VehK &V, double pz, int bits) {
+    if (V.ground_z - pz >= UAVAC_TAKEOFF_HEIGHT) bits |= UAVAC_GROUND_TAKEN_OFF;
+    const bool touching = pz - V.ground_zc > 0.0;
+    bits = touching ? (bits | UAVAC_GROUND_IN_CONTACT) : (bits & ~UAVAC_GROUND_IN_CONTACT);
+    if (touching && (bits & UAVAC_GROUND_TAKEN_OFF)) bits |= UAVAC_GROUND_HIT_AFTER_TAKEOFF;
+    return bits;
 }
 
 }  // namespace uavac_dev

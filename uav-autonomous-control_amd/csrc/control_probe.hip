@@ -123,8 +123,10 @@ __global__ void dynamics_step_kernel(const VehK V, double *__restrict__ state, i
     for (int i = 0; i < 4; ++i) om[i] = state[(13 + i) * sB + b];
     const double qn2 = X[3] * X[3] + X[4] * X[4] + X[5] * X[5] + X[6] * X[6];
     const double inv_n2 = (fabs(qn2 - 1.0) < 1.0e-12) ? 1.0 : 1.0 / qn2;
-    free_body_step(V, om, X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11], X[12], inv_n2);
+    if (V.ground) free_body_step<true>(V, om, X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11], X[12], inv_n2);
+    else free_body_step<false>(V, om, X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11], X[12], inv_n2);
     for (int i = 0; i < 13; ++i) state[i * sB + b] = X[i];
+    if (V.ground && istate) istate[3 * sB + b] = ground_bits(V, X[2], istate[3 * sB + b]);
     if (aabbs && istate) {
         int hit = 0;
         for (int o = 0; o < n_obs; ++o) {
@@ -135,10 +137,7 @@ __global__ void dynamics_step_kernel(const VehK V, double *__restrict__ state, i
     }
 }
 
-struct Scratch {
-    void *p = nullptr;
-    ~Scratch() { if (p) (void)hipFree(p); }
-};
+template <class T> T *take(uavac_ctx *ctx, size_t count) { return static_cast<T *>(uavac_arena_take(ctx, count * sizeof(T))); }
 
 template <class Kern>
 int run_probe(uavac_ctx *ctx, const uavac_vehicle *V, Kern kern, const double *in, int nin, int B, int mask,
@@ -146,14 +145,12 @@ int run_probe(uavac_ctx *ctx, const uavac_vehicle *V, Kern kern, const double *i
     UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (B < 1 || !in || !out) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
-    Scratch din, dout;
-    UAVAC_HIP(ctx, hipMalloc(&din.p, (size_t)B * nin * 8));
-    UAVAC_HIP(ctx, hipMalloc(&dout.p, (size_t)B * nout * 8));
-    UAVAC_HIP(ctx, hipMemcpyAsync(din.p, in, (size_t)B * nin * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(kern, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, uavac_make_vehk(*V),
-                       static_cast<const double *>(din.p), B, mask, static_cast<double *>(dout.p));
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size((size_t)B * nin * 8) + uavac_arena_size((size_t)B * nout * 8))) return rc;
+    double *din = take<double>(ctx, (size_t)B * nin), *dout = take<double>(ctx, (size_t)B * nout);
+    if (int rc = uavac_h2d(ctx, din, in, (size_t)B * nin * 8)) return rc;
+    hipLaunchKernelGGL(kern, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, uavac_make_vehk(*V), din, B, mask, dout);
     UAVAC_HIP(ctx, hipGetLastError());
-    UAVAC_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)B * nout * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = uavac_d2h(ctx, out, dout, (size_t)B * nout * 8)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }
@@ -197,20 +194,20 @@ int uavac_controller_tick(uavac_ctx *ctx, const uavac_vehicle *V, const double *
     UAVAC_ENTER(ctx);
     if (B < 1 || !traj || !row_offsets || !state || !istate) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
     if (row_offsets[0] != 0) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must start at 0");
-    const size_t total = (size_t)row_offsets[B];
-    Scratch dtr, dro, ds, di;
-    UAVAC_HIP(ctx, hipMalloc(&dtr.p, total * UAVAC_TRAJ_COLS * 8 + 8));
-    UAVAC_HIP(ctx, hipMalloc(&dro.p, ((size_t)B + 1) * 8));
-    UAVAC_HIP(ctx, hipMalloc(&ds.p, (size_t)B * UAVAC_STATE_ROWS * 8));
-    UAVAC_HIP(ctx, hipMalloc(&di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dtr.p, traj, total * UAVAC_TRAJ_COLS * 8, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(dro.p, row_offsets, ((size_t)B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(ds.p, state, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyHostToDevice, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(di.p, istate, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = uavac_controller_tick_dev(ctx, V, static_cast<double *>(dtr.p), static_cast<int64_t *>(dro.p),
-                                           static_cast<double *>(ds.p), static_cast<int32_t *>(di.p), B)) return rc;
-    UAVAC_HIP(ctx, hipMemcpyAsync(state, ds.p, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyDeviceToHost, ctx->stream));
-    UAVAC_HIP(ctx, hipMemcpyAsync(istate, di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t ntr = (size_t)row_offsets[B] * UAVAC_TRAJ_COLS, ns = (size_t)B * UAVAC_STATE_ROWS, ni = (size_t)B * UAVAC_ISTATE_ROWS;
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(ntr * 8) + uavac_arena_size(((size_t)B + 1) * 8) +
+                                              uavac_arena_size(ns * 8) + uavac_arena_size(ni * 4))) return rc;
+    double *dtr = take<double>(ctx, ntr);
+    int64_t *dro = take<int64_t>(ctx, (size_t)B + 1);
+    double *ds = take<double>(ctx, ns);
+    int32_t *di = take<int32_t>(ctx, ni);
+    if (int rc = uavac_h2d(ctx, dtr, traj, ntr * 8)) return rc;
+    if (int rc = uavac_h2d(ctx, dro, row_offsets, ((size_t)B + 1) * 8)) return rc;
+    if (int rc = uavac_h2d(ctx, ds, state, ns * 8)) return rc;
+    if (int rc = uavac_h2d(ctx, di, istate, ni * 4)) return rc;
+    if (int rc = uavac_controller_tick_dev(ctx, V, dtr, dro, ds, di, B)) return rc;
+    if (int rc = uavac_d2h(ctx, state, ds, ns * 8)) return rc;
+    if (int rc = uavac_d2h(ctx, istate, di, ni * 4)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }
@@ -218,21 +215,21 @@ int uavac_controller_tick(uavac_ctx *ctx, const uavac_vehicle *V, const double *
 int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate, int B,
                         const double *aabbs, int n_obs) {
     UAVAC_ENTER(ctx);
-    if (B < 1 || !state || n_obs < 0) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
-    Scratch ds, di, dab;
-    UAVAC_HIP(ctx, hipMalloc(&ds.p, (size_t)B * UAVAC_STATE_ROWS * 8));
-    UAVAC_HIP(ctx, hipMemcpyAsync(ds.p, state, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyHostToDevice, ctx->stream));
-    const bool flag = istate && aabbs && n_obs > 0;
-    if (flag) {
-        UAVAC_HIP(ctx, hipMalloc(&di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4));
-        UAVAC_HIP(ctx, hipMalloc(&dab.p, (size_t)n_obs * 48));
-        UAVAC_HIP(ctx, hipMemcpyAsync(di.p, istate, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyHostToDevice, ctx->stream));
-        UAVAC_HIP(ctx, hipMemcpyAsync(dab.p, aabbs, (size_t)n_obs * 48, hipMemcpyHostToDevice, ctx->stream));
-    }
-    if (int rc = uavac_dynamics_step_dev(ctx, V, static_cast<double *>(ds.p), flag ? static_cast<int32_t *>(di.p) : nullptr,
-                                         B, flag ? static_cast<double *>(dab.p) : nullptr, flag ? n_obs : 0)) return rc;
-    UAVAC_HIP(ctx, hipMemcpyAsync(state, ds.p, (size_t)B * UAVAC_STATE_ROWS * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (flag) UAVAC_HIP(ctx, hipMemcpyAsync(istate, di.p, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (B < 1 || !state || n_obs < 0 || !V) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    const bool obs = aabbs && n_obs > 0;
+    const bool flag = istate && (obs || V->ground);          // istate carries the obstacle flag and the ground bits
+    const size_t ns = (size_t)B * UAVAC_STATE_ROWS, ni = (size_t)B * UAVAC_ISTATE_ROWS;
+    if (int rc = uavac_arena_reserve(ctx, uavac_arena_size(ns * 8) + uavac_arena_size(ni * 4) +
+                                              uavac_arena_size((size_t)n_obs * 48))) return rc;
+    double *ds = take<double>(ctx, ns);
+    int32_t *di = flag ? take<int32_t>(ctx, ni) : nullptr;
+    double *dab = obs ? take<double>(ctx, (size_t)n_obs * 6) : nullptr;
+    if (int rc = uavac_h2d(ctx, ds, state, ns * 8)) return rc;
+    if (flag) if (int rc = uavac_h2d(ctx, di, istate, ni * 4)) return rc;
+    if (obs) if (int rc = uavac_h2d(ctx, dab, aabbs, (size_t)n_obs * 48)) return rc;
+    if (int rc = uavac_dynamics_step_dev(ctx, V, ds, di, B, dab, obs ? n_obs : 0)) return rc;
+    if (int rc = uavac_d2h(ctx, state, ds, ns * 8)) return rc;
+    if (flag) if (int rc = uavac_d2h(ctx, istate, di, ni * 4)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UAVAC_OK;
 }

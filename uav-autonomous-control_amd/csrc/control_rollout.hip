@@ -95,7 +95,7 @@ __device__ __forceinline__ VehK outer_constants() {
 // drops from 1.3 GB to 0.1 GB at B = 65 536.  Coefficients [24][64] and yaws [16][64] of a compute wave live in LDS.
 constexpr int kPolyTileDoubles = (24 + 16) * 64;
 
-template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY>
+template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND>
 __global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD) ? 64 * SW : 0))
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
@@ -191,6 +191,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     int idx = istate[0 * sB + bb];
     int inner = istate[1 * sB + bb];
     int collided = istate[2 * sB + bb];
+    int gbits = GROUND ? istate[3 * sB + bb] : 0;
 
     const int64_t off = row_offsets[bb];
     const int nrows = (int)(row_offsets[bb + 1] - off);
@@ -297,8 +298,9 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             for (int i = 0; i < 4; ++i) { c[(4 + i) * NU] = omc[i]; c[(8 + i) * NU] = om[i]; }
         }
 
-        free_body_step(V, om, px, py, pz, q0, q1, q2, q3, vx, vy, vz, wp, wq, wr, inv_n2);
+        free_body_step<GROUND>(V, om, px, py, pz, q0, q1, q2, q3, vx, vy, vz, wp, wq, wr, inv_n2);
         inv_n2 = 1.0;
+        if (GROUND) gbits = ground_bits(V, pz, gbits);
 
         if (AABB && !(LOG_STATE && CW == SW)) {            // with a state log the store wave tests the logged positions
             for (int o = 0; o < n_obs; ++o) {
@@ -335,6 +337,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     istate[0 * sB + b] = idx;
     istate[1 * sB + b] = inner;
     if (!(AABB && LOG_STATE && CW == SW)) istate[2 * sB + b] = collided;
+    if (GROUND) istate[3 * sB + b] = gbits;
 }
 
 __global__ void state_init_kernel(const VehK V, const double *__restrict__ positions, int B, int hover,
@@ -364,57 +367,54 @@ constexpr int kColumnsPerLaunch = 256 * 4 * 64;          // one 64-UAV compute w
 // launches).  After ANY kernel of 2-wave workgroups the placement is one compute + one store wave on every SIMD.
 __global__ void __launch_bounds__(128) rollout_align_kernel() {}
 
-// Workgroup shape of a logged launch (ctx->rollout_shape, uavac_set_option "rollout_shape"): 1 = one compute + one
-// store wave per 64 UAVs, preceded by the aligner (ctx->rollout_align); 4 = four compute + four store waves per 256
-// UAVs (one workgroup per CU: the dispatcher deals the 8 waves of a workgroup round the 4 SIMDs, so every SIMD gets one
-// of each whatever ran before), used for full-chip launches of 65 536 columns.
-template <int CW, int SW, bool LS, bool LC, bool AB, bool POLY>
+// One compute + one store wave per 64 UAVs.  (Four compute + four store waves per 256 UAVs -- one workgroup per CU, whose
+// 8 waves the dispatcher always deals round the 4 SIMDs evenly, so that no aligner is needed -- was measured at 1.65 ms
+// per 1 000 ticks against 1.33 ms: the per-tick barrier then couples eight waves.  The kernel keeps its CW / SW
+// parameters; only <1, 1> is instantiated.)
+template <bool LS, bool LC, bool AB, bool POLY, bool GR>
 void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                   int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
-                  const PlanRef &P, int base, int cols) {
+                  const PlanRef &P) {
+    constexpr int CW = 1, SW = 1;
+    constexpr bool LOGGING = LS || LC;
     constexpr int NU = 64 * CW;
     constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0);
-    constexpr int threads = NU + ((LS || LC) ? 64 * SW : 0);
+    constexpr int threads = NU + (LOGGING ? 64 * SW : 0);
     const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * kPolyTileDoubles : 0));
-    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY>;
+    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((cols + NU - 1) / NU), dim3(threads), lds, ctx->stream, V, traj, row_offsets, state,
-                       istate, B, K, state_log, cmd_log, aabbs, n_obs, base, P);
-    auto tf = [](bool v) { return v ? "true" : "false"; };
-    char name[160];
-    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY));
-    ctx->last_rollout = name;
-}
-
-template <bool LS, bool LC, bool AB, bool POLY>
-void launch_poly(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
-                 int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
-                 const PlanRef &P) {
-    constexpr bool LOGGING = LS || LC;
     // With logs, batches beyond one compute wave per SIMD go out as consecutive launches of kColumnsPerLaunch UAVs:
     // measured per 1 000 ticks, B = 131 072 in one launch 4.04 ms, as 2 x 65 536 3.3 ms (two workgroups per SIMD
     // make the compute and store waves of a CU queue on each other).  Results do not depend on the split.
     const int per_launch = LOGGING ? kColumnsPerLaunch : B;
     for (int base = 0; base < B; base += per_launch) {
         const int cols = (B - base < per_launch) ? B - base : per_launch;
-#define UAVAC_SHAPE_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, P, base, cols
-        if (LOGGING && ctx->rollout_shape == 4 && cols == kColumnsPerLaunch) {
-            launch_shape<4, 4, LS, LC, AB, POLY>(UAVAC_SHAPE_ARGS);
-        } else {
-            if (LOGGING && ctx->rollout_align)
-                hipLaunchKernelGGL(rollout_align_kernel, dim3((cols + 63) / 64), dim3(128), 0, ctx->stream);
-            launch_shape<1, 1, LS, LC, AB, POLY>(UAVAC_SHAPE_ARGS);
-        }
-#undef UAVAC_SHAPE_ARGS
+        const int grid = (cols + NU - 1) / NU;
+        if (LOGGING && ctx->rollout_align)
+            hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(128), 0, ctx->stream);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, V, traj, row_offsets, state, istate, B, K,
+                           state_log, cmd_log, aabbs, n_obs, base, P);
     }
+    auto tf = [](bool v) { return v ? "true" : "false"; };
+    char name[176];
+    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
+             tf(GR));
+    ctx->last_rollout = name;
 }
 
 template <bool LS, bool LC, bool AB>
 void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                     int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                     const PlanRef *plan) {
-    if (plan) launch_poly<LS, LC, AB, true>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, *plan);
-    else launch_poly<LS, LC, AB, false>(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, PlanRef{});
+#define UAVAC_SHAPE_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs
+    if (plan) {
+        if (V.ground) launch_shape<LS, LC, AB, true, true>(UAVAC_SHAPE_ARGS, *plan);
+        else launch_shape<LS, LC, AB, true, false>(UAVAC_SHAPE_ARGS, *plan);
+    } else {
+        if (V.ground) launch_shape<LS, LC, AB, false, true>(UAVAC_SHAPE_ARGS, PlanRef{});
+        else launch_shape<LS, LC, AB, false, false>(UAVAC_SHAPE_ARGS, PlanRef{});
+    }
+#undef UAVAC_SHAPE_ARGS
 }
 
 void launch_flags(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,

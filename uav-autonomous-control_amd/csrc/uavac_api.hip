@@ -16,7 +16,11 @@ constexpr size_t kStageChunk = (size_t)8 << 20;       // bytes per half of the p
 // Host <-> device copies of the host-pointer twins.  The caller's buffers are pageable; they travel through the ctx's
 // pinned staging buffer in kStageChunk pieces, two halves in flight: the DMA of one piece overlaps the CPU copy of the
 // next (h2d) or previous (d2h) one.  Ordered on the ctx stream like everything else.
-int h2d_staged(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+int h2d_staged(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) { return uavac_h2d(ctx, dst_dev, src_host, bytes); }
+int d2h_staged(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) { return uavac_d2h(ctx, dst_host, src_dev, bytes); }
+}  // namespace
+
+int uavac_h2d(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (!bytes) return UAVAC_OK;
     if (int rc = uavac_pin_reserve(ctx, 2 * kStageChunk)) return rc;
     const char *src = static_cast<const char *>(src_host);
@@ -36,7 +40,7 @@ int h2d_staged(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes
     return UAVAC_OK;
 }
 
-int d2h_staged(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+int uavac_d2h(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     if (!bytes) return UAVAC_OK;
     if (int rc = uavac_pin_reserve(ctx, 2 * kStageChunk)) return rc;
     char *dst = static_cast<char *>(dst_host);
@@ -58,6 +62,8 @@ int d2h_staged(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
     }
     return UAVAC_OK;
 }
+
+namespace {
 
 template <class T> T *take(uavac_ctx *ctx, size_t count) { return static_cast<T *>(uavac_arena_take(ctx, count * sizeof(T))); }
 
@@ -159,6 +165,11 @@ VehK uavac_make_vehk(const uavac_vehicle &V) {
     k.ikp[0] = V.inertia[0] * V.kp_p; k.ikp[1] = V.inertia[1] * V.kp_q; k.ikp[2] = V.inertia[2] * V.kp_r;
     k.hover_omega = std::sqrt(V.mass * V.g / (4.0 * V.kf));
     k.F = V.inner_per_outer;
+    k.ground = V.ground ? 1 : 0;
+    k.ground_z = V.ground_z;
+    k.ground_zc = V.ground_z - V.ground_clearance;
+    k.ground_k = k.ground ? 1.0 / (V.ground_timeconst * V.ground_timeconst) : 0.0;
+    k.ground_b = k.ground ? 2.0 / V.ground_timeconst : 0.0;
     return k;
 }
 
@@ -171,6 +182,13 @@ int uavac_check_vehicle(uavac_ctx *ctx, const uavac_vehicle *V) {
     if (!(V->min_thrust >= 0.0) || !(V->max_thrust > V->min_thrust))
         return uavac_fail(ctx, UAVAC_EINVAL, "thrust limits must satisfy 0 <= min < max");
     if (V->inner_per_outer < 1) return uavac_fail(ctx, UAVAC_EINVAL, "inner_per_outer must be >= 1");
+    if (V->ground) {
+        if (!std::isfinite(V->ground_z) || !(V->ground_clearance >= 0.0) || !std::isfinite(V->ground_clearance) ||
+            !(V->ground_timeconst > 0.0) || !std::isfinite(V->ground_timeconst))
+            return uavac_fail(ctx, UAVAC_EINVAL, "ground plane needs finite z, clearance >= 0 and time constant > 0");
+        if (!(V->ground_timeconst >= 2.0 * V->dt))      // the explicit step of the contact law is stable for dt <= tc / 2
+            return uavac_fail(ctx, UAVAC_EINVAL, "ground_timeconst must be at least 2 dt");
+    }
     return UAVAC_OK;
 }
 
@@ -202,7 +220,6 @@ int uavac_create(uavac_ctx **out, int device_id) {
         delete ctx;
         return UAVAC_EHIP;
     }
-    if (const char *e = getenv("UAVAC_ROLLOUT_SHAPE")) ctx->rollout_shape = (e[0] == '4') ? 4 : 1;
     if (const char *e = getenv("UAVAC_ROLLOUT_ALIGN")) ctx->rollout_align = (e[0] == '0') ? 0 : 1;
     *out = ctx;
     return UAVAC_OK;
@@ -248,10 +265,7 @@ int uavac_device(const uavac_ctx *ctx) { return ctx ? ctx->device : UAVAC_EINVAL
 int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return UAVAC_EINVAL;
     const std::string n(name);
-    if (n == "rollout_shape") {
-        if (value != 1 && value != 4) return uavac_fail(ctx, UAVAC_EINVAL, "rollout_shape is 1 or 4");
-        ctx->rollout_shape = value;
-    } else if (n == "rollout_align") {
+    if (n == "rollout_align") {
         ctx->rollout_align = value ? 1 : 0;
     } else {
         return uavac_fail(ctx, UAVAC_EINVAL, "unknown option");
@@ -281,6 +295,8 @@ void uavac_vehicle_default(uavac_vehicle *V) {
     V->ki_z = 0.1;
     V->kp_roll = 1.0 / 0.07; V->kp_pitch = 1.0 / 0.07; V->kp_yaw = 1.0 / 0.25;
     V->kp_p = 1.0 / 0.008; V->kp_q = 1.0 / 0.008; V->kp_r = 1.0 / 0.09;
+    // free flight by default; the plane of lab_course.xml:34 and the body box of :101 when switched on
+    V->ground = 0; V->ground_z = 0.0; V->ground_clearance = 0.02; V->ground_timeconst = 0.02;
 }
 
 // ------------------------------------------------------------------------------- planning, device

@@ -28,7 +28,6 @@ struct uavac_ctx {
     size_t pin_cap = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::string err;
-    int rollout_shape = 1;           // tuning (uavac_set_option): workgroup shape of logged rollout launches, 1 or 4
     int rollout_align = 1;           // tuning: launch the 2-wave aligner kernel before a logged launch of shape 1
     std::string last_rollout;        // name and template arguments of the rollout kernel launched last (diagnostics)
 };
@@ -100,6 +99,10 @@ static inline size_t uavac_arena_size(size_t bytes) { return (bytes + 255) & ~(s
 int uavac_scratch(uavac_ctx *ctx, size_t bytes, void **out);
 // Pinned staging: at least `bytes` of page-locked host memory in ctx->h_pin.
 int uavac_pin_reserve(uavac_ctx *ctx, size_t bytes);
+// Pageable host buffer <-> device through the pinned ping-pong buffer, ordered on the ctx stream (uavac_api.hip).
+// h2d returns once the source has been read; d2h once the destination holds the data.
+int uavac_h2d(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int uavac_d2h(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 // Kernel-side view of uavac_vehicle with the per-call constants hoisted on the host.
 struct VehK {
@@ -112,7 +115,9 @@ struct VehK {
     double kp_xy, kd_xy, kp_z, kd_z, ki_z, kp_roll, kp_pitch, kp_yaw;
     double ikp[3];                   // I * kp_pqr: controller.py:128
     double hover_omega;
+    double ground_zc, ground_k, ground_b, ground_z;   // contact starts at pz > ground_zc = ground_z - clearance; 1/tc^2, 2/tc
     int F;
+    int ground;
 };
 
 VehK uavac_make_vehk(const uavac_vehicle &V);

@@ -18,7 +18,9 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libuavac.so")
 OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
 MAX_SEGMENTS = 64
-TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 26, 3, 12
+TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 26, 4, 12
+VERSION = 200
+GROUND_IN_CONTACT, GROUND_TAKEN_OFF, GROUND_HIT_AFTER_TAKEOFF = 1, 2, 4       # istate row 3 (include/uavac.h)
 
 
 class UavacError(RuntimeError):
@@ -34,7 +36,8 @@ class Vehicle(C.Structure):
                    "arm", "kf", "kappa", "min_thrust", "max_thrust", "tau_rise", "tau_fall",
                    "max_ascent", "max_descent", "max_speed_xy", "max_horiz_accel", "max_tilt",
                    "kp_xy", "kd_xy", "kp_z", "kd_z", "ki_z", "kp_roll", "kp_pitch", "kp_yaw",
-                   "kp_p", "kp_q", "kp_r")] + [("inner_per_outer", C.c_int32), ("reserved", C.c_int32)]
+                   "kp_p", "kp_q", "kp_r")] + [("inner_per_outer", C.c_int32), ("ground", C.c_int32)] + \
+               [(n, C.c_double) for n in ("ground_z", "ground_clearance", "ground_timeconst")]
 
     @classmethod
     def default(cls) -> "Vehicle":

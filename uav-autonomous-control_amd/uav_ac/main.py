@@ -76,7 +76,7 @@ class FreeFlightSimulation:
         state = np.zeros((nat.STATE_ROWS, 1))
         state[0:13, 0] = q.X
         state[13:17, 0] = q.omega
-        istate = np.zeros((3, 1), dtype=np.int32)
+        istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
         n_obs = 0 if self.obstacles is None else len(self.obstacles)
         ctx().call("uavac_dynamics_step", C.byref(V), nat.np_ptr(state), nat.np_ptr(istate), 1,
                    nat.np_ptr(self.obstacles), n_obs)
@@ -99,13 +99,15 @@ def _generate_mission_trajectory(waypoints: np.ndarray, obstacles, velocity: flo
 
 
 def fly_mission(model_path, velocity: float = 3.0, frequency: int = 10, min_distance_target: float = 0.5,
-                settle_ticks: int = 2000):
-    """Head-less equivalent of the reference's `main()` (main.py:87-120) in free flight: read the scene,
-    plan takeoff + course around its obstacles, fly it, report.  The whole flight is ONE fused rollout on the
-    GPU (B = 1) with the per-tick AABB flag; no viewer, no ground contact.
+                settle_ticks: int = 2000, ground: bool = True):
+    """Head-less equivalent of the reference's `main()` (main.py:87-120): read the scene, plan takeoff + course
+    around its obstacles, fly it from the scene's start state -- on the ground, rotors stopped (lab_course.xml:98)
+    -- and report.  The whole flight is ONE fused rollout on the GPU (B = 1) with the per-tick AABB flag and, when
+    the scene has a ground plane and `ground` is true, the build-defined ground contact + take-off bookkeeping
+    (include/uavac.h, `uavac_vehicle.ground`); `ground=False` flies the same mission in free flight.  No viewer.
 
-    Returns a dict: trajectory (N,11), states (K,13), distance_to_goal, goal_reached, collision_detected,
-    mean_tracking_error.
+    Returns a dict: trajectory (N,11), states (K,13), distance_to_goal, goal_reached, collision_detected (an obstacle
+    entered, or the ground touched after take-off: mujoco_sim.py:220-230), ground_bits, mean_tracking_error.
     """
     from .fleet import Engine
     from .simulation.mujoco_sim import MujocoSimulation
@@ -119,11 +121,13 @@ def fly_mission(model_path, velocity: float = 3.0, frequency: int = 10, min_dist
     torch = eng._torch
     rows = torch.as_tensor(trajectory, dtype=torch.float64, device=eng.device).contiguous()
     offsets = torch.tensor([0, len(trajectory)], dtype=torch.int64, device=eng.device)
-    V = vehicle_from(quad, dt_outer=dt_traj)
+    V = sim.vehicle(dt_outer=dt_traj)
+    if not ground:
+        V.ground = 0
     V.inner_per_outer = int(frequency)
     state = torch.zeros((nat.STATE_ROWS, 1), dtype=torch.float64, device=eng.device)
     state[0:13, 0] = torch.as_tensor(quad.X)
-    istate = torch.zeros((3, 1), dtype=torch.int32, device=eng.device)
+    istate = torch.zeros((nat.ISTATE_ROWS, 1), dtype=torch.int32, device=eng.device)
     K = len(trajectory) * frequency + settle_ticks
     log = torch.empty((K, 13, 1), dtype=torch.float64, device=eng.device)
     aabbs = torch.as_tensor(sim.obstacles, dtype=torch.float64, device=eng.device).contiguous()
@@ -137,8 +141,9 @@ def fly_mission(model_path, velocity: float = 3.0, frequency: int = 10, min_dist
     err = np.linalg.norm(states[::frequency][:n, 0:3] - trajectory[:n, 0:3], axis=1)
     dist = float(np.linalg.norm(quad.position - sim.goal_position))
     return {"trajectory": trajectory, "states": states, "distance_to_goal": dist,
-            "goal_reached": dist < min_distance_target, "collision_detected": bool(istate[2, 0].item()),
-            "mean_tracking_error": float(err.mean())}
+            "goal_reached": dist < min_distance_target,
+            "collision_detected": bool(istate[2, 0].item()) or bool(int(istate[3, 0].item()) & nat.GROUND_HIT_AFTER_TAKEOFF),
+            "ground_bits": int(istate[3, 0].item()), "mean_tracking_error": float(err.mean())}
 
 
 def main(model_path=None) -> None:

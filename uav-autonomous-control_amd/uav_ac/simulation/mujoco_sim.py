@@ -1,12 +1,18 @@
-"""Free-flight stand-in for the reference's `uav_ac/simulation/mujoco_sim.py`.
+"""MuJoCo-free stand-in for the reference's `uav_ac/simulation/mujoco_sim.py`.
 
 `MujocoSimulation(model_path)` reads the MJCF scene WITHOUT MuJoCo (plain XML: vehicle constants from
 `<custom><numeric>`, body mass / inertia, rotor sites and spin signs, `waypoint_NN` / `goal` sites,
 `obstacle_*` boxes) into the same attributes the reference adapter exposes -- `quad`,
 `mission_waypoints`, `obstacles`, `start_position`, `goal_position`, `space_limits` -- and `step()`
 advances the vehicle on the GPU with the build-defined free-body step (`uavac_dynamics_step`): rotor
-wrench + semi-implicit Euler, no ground, no contacts, no viewer.  Validation errors mirror the
-reference's `ValueError`s (mujoco_sim.py:261-266, 289-291, 317-320, 331-332, 339-347).
+wrench + semi-implicit Euler, no viewer.  The vehicle starts where the scene puts it -- ON THE GROUND with
+stopped rotors, like the reference (lab_course.xml:98, mujoco_sim.py:190-199) -- when the scene has a `ground`
+plane: the plane and the half height of the `body` box go into `uavac_vehicle.ground*`, the contact is the
+build-defined one of control_law.h (critically damped normal push, no friction, no torque; NOT MuJoCo's solver:
+contact forces are not comparable), and the take-off bookkeeping of `_record_collisions` (:220-230) comes back in
+istate row 3.  Collisions with obstacles are the position-in-AABB test (the reference asks MuJoCo for geometry
+contacts).  Validation errors mirror the reference's `ValueError`s (mujoco_sim.py:261-266, 289-291, 317-320,
+331-332, 339-347).
 
 Only world-frame geometry directly under `<worldbody>` is understood (that is all the reference's
 scene uses for planning data); `<replicate>` visual helpers and assets are ignored.
@@ -132,7 +138,14 @@ class MujocoSimulation:
             h = _floats(geom.get("size"), 3, name)
             obstacles.append([c[0] - h[0], c[0] + h[0], c[1] - h[1], c[1] + h[1], c[2] - h[2], c[2] + h[2]])
         self.obstacles = np.asarray(obstacles, dtype=float).reshape(-1, 6)
+        # ground plane (lab_course.xml:34) and the body box that rests on it (:101): NED height of the plane and the
+        # distance from the body centre to its lowest point
+        ground = next((g_ for g_ in world.findall("geom") if g_.get("name") == "ground" and g_.get("type") == "plane"), None)
+        box = next((g_ for g_ in body.findall("geom") if g_.get("name") == "body" and g_.get("type", "sphere") == "box"), None)
+        self.ground_z = None if ground is None else float(-_floats(ground.get("pos", "0 0 0"), 3, "ground")[2])
+        self.ground_clearance = 0.0 if box is None else float(_floats(box.get("size"), 3, "body size")[2])
         self._collision_detected = False
+        self._ground_bits = 0
         if self.has_collision:
             raise ValueError("quadrotor starts in collision")
 
@@ -143,17 +156,29 @@ class MujocoSimulation:
             raise ValueError(f"MuJoCo numeric '{name}' must contain {expected_size} values")
         return self._numerics[name].copy()
 
+    def vehicle(self, **kw) -> nat.Vehicle:
+        """`uavac_vehicle` of this scene: the quad's constants and gains + the ground plane when the scene has one."""
+        V = vehicle_from(self.quad, **kw)
+        if self.ground_z is not None:
+            V.ground, V.ground_z, V.ground_clearance = 1, self.ground_z, self.ground_clearance
+        return V
+
+    def _touches_ground(self) -> bool:
+        return self.ground_z is not None and bool(self.quad.position[2] - (self.ground_z - self.ground_clearance) > 0.0)
+
     @property
     def has_collision(self) -> bool:
-        """The vehicle's position is inside a planning obstacle right now (the reference asks MuJoCo for contacts,
-        mujoco_sim.py:93-96; free flight has no ground and no body geometry, so this is the position test)."""
+        """The vehicle touches world geometry right now (reference mujoco_sim.py:93-96 asks MuJoCo for contacts): its
+        lowest point is below the ground plane, or its position is inside a planning obstacle."""
         p, o = self.quad.position, self.obstacles
-        return bool(len(o)) and bool(np.any((p[0] >= o[:, 0]) & (p[0] <= o[:, 1]) & (p[1] >= o[:, 2]) & (p[1] <= o[:, 3]) &
-                                            (p[2] >= o[:, 4]) & (p[2] <= o[:, 5])))
+        inside = bool(len(o)) and bool(np.any((p[0] >= o[:, 0]) & (p[0] <= o[:, 1]) & (p[1] >= o[:, 2]) & (p[1] <= o[:, 3]) &
+                                              (p[2] >= o[:, 4]) & (p[2] <= o[:, 5])))
+        return inside or self._touches_ground()
 
     @property
     def collision_detected(self) -> bool:
-        """Sticky: the vehicle's position has been inside a planning obstacle (inclusive AABB test)."""
+        """Sticky (reference :98-101, 220-230): an obstacle has been entered, or the ground touched after take-off
+        (ground contact before reaching TAKEOFF_HEIGHT is the start, not a collision)."""
         return self._collision_detected
 
     def step(self) -> np.ndarray:
@@ -162,10 +187,13 @@ class MujocoSimulation:
         state = np.zeros((nat.STATE_ROWS, 1))
         state[0:13, 0] = q.X
         state[13:17, 0] = q.omega
-        istate = np.zeros((3, 1), dtype=np.int32)
+        istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
+        istate[3, 0] = self._ground_bits
         n_obs = len(self.obstacles)
-        ctx().call("uavac_dynamics_step", C.byref(vehicle_from(q)), nat.np_ptr(state), nat.np_ptr(istate), 1,
+        ctx().call("uavac_dynamics_step", C.byref(self.vehicle()), nat.np_ptr(state), nat.np_ptr(istate), 1,
                    nat.np_ptr(self.obstacles) if n_obs else None, n_obs)
         q.X = state[0:13, 0].copy()
-        self._collision_detected = self._collision_detected or bool(istate[2, 0])
+        self._ground_bits = int(istate[3, 0])
+        self._collision_detected = (self._collision_detected or bool(istate[2, 0]) or
+                                    bool(self._ground_bits & nat.GROUND_HIT_AFTER_TAKEOFF))
         return q.X.copy()
