@@ -259,6 +259,28 @@ int uavac_controller_tick(uavac_ctx *ctx, const uavac_vehicle *V, const double *
 int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, int32_t *istate, int B,
                         const double *aabbs, int n_obs);
 
+/* ---- resident tick-by-tick session ----------------------------------------------
+ * For callers that own the loop like uav_ac/main.py:113-118 does -- `tc.step(); simulation.step()`
+ * once per inner tick, with host code reading and writing quad.X / quad.omega in between.  The
+ * trajectory rows of the B UAVs are uploaded once at creation; the state lives in pinned host memory
+ * that is mapped into the device and that the tick kernels read and write IN PLACE:
+ * uavac_pilot_state() -> [26][B] f64, uavac_pilot_istate() -> [4][B] i32 (layouts above), valid until
+ * uavac_pilot_destroy.  uavac_pilot_tick runs the controller half (uavac_controller_tick), the
+ * vehicle half (uavac_dynamics_step) or both on that state and returns when the results are
+ * visible to the host: one kernel launch (or two) and one stream synchronisation per call, no
+ * copies, no allocation.  The host may edit the state between calls (that is what the reference's
+ * tests do to quad.X). */
+typedef struct uavac_pilot uavac_pilot;
+#define UAVAC_PILOT_CONTROLLER 1
+#define UAVAC_PILOT_DYNAMICS 2
+int uavac_pilot_create(uavac_ctx *ctx, const double *traj, const int64_t *row_offsets, int B,
+                       uavac_pilot **out);                 /* traj / row_offsets: HOST pointers */
+void uavac_pilot_destroy(uavac_pilot *pilot);
+double *uavac_pilot_state(uavac_pilot *pilot);
+int32_t *uavac_pilot_istate(uavac_pilot *pilot);
+int uavac_pilot_set_obstacles(uavac_pilot *pilot, const double *aabbs, int n_obs);   /* HOST [n_obs][6] */
+int uavac_pilot_tick(uavac_pilot *pilot, const uavac_vehicle *V, int what);
+
 /* ---- per-function probes ------------------------------------------------------
  * One stage of the control law at a time on small array-of-struct batches (host pointers,
  * synchronous).  They run the very __device__ functions the fused rollout inlines, so the

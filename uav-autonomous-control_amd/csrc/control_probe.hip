@@ -6,6 +6,9 @@
 
 #include "control_law.h"
 
+#include <cstring>
+#include <new>
+
 namespace {
 
 using namespace uavac_dev;
@@ -231,6 +234,101 @@ int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, i
     if (int rc = uavac_d2h(ctx, state, ds, ns * 8)) return rc;
     if (flag) if (int rc = uavac_d2h(ctx, istate, di, ni * 4)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UAVAC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Resident tick-by-tick session for callers that own the loop the way uav_ac/main.py does (tc.step(); sim.step() per
+// inner tick, with Python reading and writing quad.X / quad.omega in between).  The trajectory rows are uploaded ONCE;
+// the (small) state lives in pinned, device-mapped host memory that the kernels read and write in place, so a tick is
+// one kernel launch + one stream synchronisation -- no staging copies, no allocation.
+struct uavac_pilot {
+    uavac_ctx *ctx = nullptr;
+    int B = 0;
+    double *d_traj = nullptr;
+    int64_t *d_offsets = nullptr;
+    double *d_aabbs = nullptr;
+    int n_obs = 0;
+    double *h_state = nullptr;       // pinned + mapped: [26][B]
+    int32_t *h_istate = nullptr;     // pinned + mapped: [4][B]
+};
+
+int uavac_pilot_create(uavac_ctx *ctx, const double *traj, const int64_t *row_offsets, int B, uavac_pilot **out) {
+    UAVAC_ENTER(ctx);
+    if (!out) return uavac_fail(ctx, UAVAC_EINVAL, "null output pointer");
+    *out = nullptr;
+    if (B < 1 || !traj || !row_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    if (row_offsets[0] != 0) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must start at 0");
+    for (int b = 0; b < B; ++b)
+        if (row_offsets[b + 1] < row_offsets[b]) return uavac_fail(ctx, UAVAC_EINVAL, "row_offsets must be non-decreasing");
+    uavac_pilot *p = new (std::nothrow) uavac_pilot();
+    if (!p) return UAVAC_ENOMEM;
+    p->ctx = ctx;
+    p->B = B;
+    const size_t ntr = (size_t)row_offsets[B] * UAVAC_TRAJ_COLS;
+    auto fail = [&](int rc) { uavac_pilot_destroy(p); return rc; };
+    if (hipMalloc(&p->d_traj, ntr * 8 + 8) != hipSuccess || hipMalloc(&p->d_offsets, ((size_t)B + 1) * 8) != hipSuccess ||
+        hipHostMalloc(&p->h_state, (size_t)B * UAVAC_STATE_ROWS * 8, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(&p->h_istate, (size_t)B * UAVAC_ISTATE_ROWS * 4, hipHostMallocMapped) != hipSuccess)
+        return fail(uavac_fail(ctx, UAVAC_EHIP, "pilot allocation failed"));
+    std::memset(p->h_state, 0, (size_t)B * UAVAC_STATE_ROWS * 8);
+    std::memset(p->h_istate, 0, (size_t)B * UAVAC_ISTATE_ROWS * 4);
+    if (int rc = uavac_h2d(ctx, p->d_traj, traj, ntr * 8)) return fail(rc);
+    if (int rc = uavac_h2d(ctx, p->d_offsets, row_offsets, ((size_t)B + 1) * 8)) return fail(rc);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(uavac_fail(ctx, UAVAC_EHIP, "pilot upload failed"));
+    *out = p;
+    return UAVAC_OK;
+}
+
+void uavac_pilot_destroy(uavac_pilot *p) {
+    if (!p) return;
+    uavac_device_guard guard(p->ctx);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->d_traj) (void)hipFree(p->d_traj);
+    if (p->d_offsets) (void)hipFree(p->d_offsets);
+    if (p->d_aabbs) (void)hipFree(p->d_aabbs);
+    if (p->h_state) (void)hipHostFree(p->h_state);
+    if (p->h_istate) (void)hipHostFree(p->h_istate);
+    delete p;
+}
+
+double *uavac_pilot_state(uavac_pilot *p) { return p ? p->h_state : nullptr; }
+int32_t *uavac_pilot_istate(uavac_pilot *p) { return p ? p->h_istate : nullptr; }
+
+int uavac_pilot_set_obstacles(uavac_pilot *p, const double *aabbs, int n_obs) {
+    if (!p) return UAVAC_EINVAL;
+    uavac_ctx *ctx = p->ctx;
+    UAVAC_ENTER(ctx);
+    if (n_obs < 0 || (n_obs > 0 && !aabbs)) return uavac_fail(ctx, UAVAC_EINVAL, "bad obstacle list");
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (p->d_aabbs) UAVAC_HIP(ctx, hipFree(p->d_aabbs));
+    p->d_aabbs = nullptr;
+    p->n_obs = 0;
+    if (n_obs > 0) {
+        UAVAC_HIP(ctx, hipMalloc(&p->d_aabbs, (size_t)n_obs * 48));
+        if (int rc = uavac_h2d(ctx, p->d_aabbs, aabbs, (size_t)n_obs * 48)) return rc;
+        UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        p->n_obs = n_obs;
+    }
+    return UAVAC_OK;
+}
+
+int uavac_pilot_tick(uavac_pilot *p, const uavac_vehicle *V, int what) {
+    if (!p) return UAVAC_EINVAL;
+    uavac_ctx *ctx = p->ctx;
+    UAVAC_ENTER(ctx);
+    if (int rc = uavac_check_vehicle(ctx, V)) return rc;
+    if (!(what & (UAVAC_PILOT_CONTROLLER | UAVAC_PILOT_DYNAMICS))) return uavac_fail(ctx, UAVAC_EINVAL, "nothing to do");
+    const VehK K = uavac_make_vehk(*V);
+    const dim3 grid((p->B + 63) / 64), block(64);
+    if (what & UAVAC_PILOT_CONTROLLER)
+        hipLaunchKernelGGL(controller_tick_kernel, grid, block, 0, ctx->stream, K, p->d_traj, p->d_offsets, p->h_state,
+                           p->h_istate, p->B);
+    if (what & UAVAC_PILOT_DYNAMICS)
+        hipLaunchKernelGGL(dynamics_step_kernel, grid, block, 0, ctx->stream, K, p->h_state, p->h_istate, p->B,
+                           p->n_obs > 0 ? p->d_aabbs : nullptr, p->n_obs);
+    UAVAC_HIP(ctx, hipGetLastError());
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the caller reads the pinned state next
     return UAVAC_OK;
 }
 

@@ -11,7 +11,11 @@
 
 namespace {
 
-constexpr size_t kStageChunk = (size_t)8 << 20;       // bytes per half of the pinned ping-pong buffer
+constexpr size_t kStageChunk = (size_t)1 << 20;       // bytes per half of the pinned ping-pong buffer
+// Transfers up to this size go through the ctx's own pinned buffer (no pinning work inside the runtime, no allocation);
+// larger ones are handed to hipMemcpyAsync as they are: the runtime's pageable path moves them at 50 GB/s aggregate
+// (H2D + D2H of a 4 096-UAV rollout, tools/host_path_rate.py), a single-threaded copy through a staging buffer at 27.
+constexpr size_t kStageLimit = (size_t)1 << 20;
 
 // Host <-> device copies of the host-pointer twins.  The caller's buffers are pageable; they travel through the ctx's
 // pinned staging buffer in kStageChunk pieces, two halves in flight: the DMA of one piece overlaps the CPU copy of the
@@ -22,6 +26,10 @@ int d2h_staged(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
 
 int uavac_h2d(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (!bytes) return UAVAC_OK;
+    if (bytes > kStageLimit) {
+        UAVAC_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return UAVAC_OK;                  // pageable source: the runtime has read it when the call returns
+    }
     if (int rc = uavac_pin_reserve(ctx, 2 * kStageChunk)) return rc;
     const char *src = static_cast<const char *>(src_host);
     char *dst = static_cast<char *>(dst_dev);
@@ -42,6 +50,11 @@ int uavac_h2d(uavac_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 
 int uavac_d2h(uavac_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     if (!bytes) return UAVAC_OK;
+    if (bytes > kStageLimit) {
+        UAVAC_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return UAVAC_OK;
+    }
     if (int rc = uavac_pin_reserve(ctx, 2 * kStageChunk)) return rc;
     char *dst = static_cast<char *>(dst_host);
     const char *src = static_cast<const char *>(src_dev);

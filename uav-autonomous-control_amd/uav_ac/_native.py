@@ -91,6 +91,12 @@ _SIGNATURES = {
     "uavac_dynamics_step_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, C.c_int, _P, C.c_int]),
     "uavac_controller_tick": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
     "uavac_dynamics_step": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, C.c_int, _P, C.c_int]),
+    "uavac_pilot_create": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(_P)]),
+    "uavac_pilot_destroy": (None, [_P]),
+    "uavac_pilot_state": (C.POINTER(C.c_double), [_P]),
+    "uavac_pilot_istate": (C.POINTER(C.c_int32), [_P]),
+    "uavac_pilot_set_obstacles": (C.c_int, [_P, _P, C.c_int]),
+    "uavac_pilot_tick": (C.c_int, [_P, C.POINTER(Vehicle), C.c_int]),
     "uavac_probe_outer": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
     "uavac_probe_inner": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
     "uavac_rrt_star_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 7),
@@ -218,6 +224,41 @@ class Context:
 
     def last_rollout_kernel(self) -> str:
         return (lib().uavac_last_rollout_kernel(self._h) or b"").decode()
+
+
+PILOT_CONTROLLER, PILOT_DYNAMICS = 1, 2
+
+
+class Pilot:
+    """Resident tick-by-tick session (`uavac_pilot_*`): trajectory rows on the device, state in pinned mapped host memory
+    exposed as NumPy views `state` (26, B) and `istate` (4, B) that the kernels update in place."""
+
+    def __init__(self, ctx: Context, traj: np.ndarray, row_offsets: np.ndarray):
+        self._ctx = ctx
+        self._h = _P()
+        traj = as_f64(traj)
+        offs = np.ascontiguousarray(row_offsets, dtype=np.int64)
+        self.B = len(offs) - 1
+        ctx.check(lib().uavac_pilot_create(ctx._h, np_ptr(traj), np_ptr(offs), self.B, C.byref(self._h)))
+        self.state = np.ctypeslib.as_array(lib().uavac_pilot_state(self._h), shape=(STATE_ROWS, self.B))
+        self.istate = np.ctypeslib.as_array(lib().uavac_pilot_istate(self._h), shape=(ISTATE_ROWS, self.B))
+
+    def set_obstacles(self, aabbs):
+        a = None if aabbs is None else as_f64(aabbs).reshape(-1, 6)
+        n = 0 if a is None else len(a)
+        self._ctx.check(lib().uavac_pilot_set_obstacles(self._h, np_ptr(a) if n else None, n))
+
+    def tick(self, vehicle: Vehicle, what: int = PILOT_CONTROLLER | PILOT_DYNAMICS):
+        self._ctx.check(lib().uavac_pilot_tick(self._h, C.byref(vehicle), int(what)))
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and _lib is not None and self._ctx._h.value:
+            self.state = self.istate = None
+            _lib.uavac_pilot_destroy(h)
+            self._h = _P()
+
+    __del__ = close
 
 
 def np_ptr(a: np.ndarray | None):

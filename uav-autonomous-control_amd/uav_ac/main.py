@@ -34,30 +34,39 @@ class TrajectoryController:
         self.thrust_cmd = 0.0
         self.pqr_cmd.fill(0.0)
 
+    def _pilot(self) -> nat.Pilot:
+        """Resident session for this trajectory (`uavac_pilot_*`): the rows go to the GPU once, not once per tick."""
+        traj = self.trajectory
+        key = (id(traj), getattr(traj, "shape", None), traj.ctypes.data if isinstance(traj, np.ndarray) else None)
+        if getattr(self, "_pilot_key", None) != key:
+            rows = nat.as_f64(traj)
+            self._pilot_obj = nat.Pilot(ctx(), rows, np.array([0, len(rows)], dtype=np.int64))
+            self._pilot_key = key
+        return self._pilot_obj
+
     def step(self) -> None:
-        """One `tc.step()` of the reference (main.py:37-61) on the GPU."""
+        """One `tc.step()` of the reference (main.py:37-61) on the GPU: `uavac_pilot_tick` (controller half) on state
+        that lives in pinned memory the kernel reads and writes in place."""
         q = self.quad
         V = vehicle_from(q, g=self.controller.g, dt_outer=self.controller.dt)
         V.inner_per_outer = int(self.inner_loop_frequency)
-        traj = nat.as_f64(self.trajectory)
-        state = np.zeros((nat.STATE_ROWS, 1))
-        state[0:13, 0] = q.X
-        state[13:17, 0] = q.omega
-        state[17:21, 0] = q.omega_command
-        state[21, 0] = self.controller.integral_error
-        state[22, 0] = self.thrust_cmd
-        state[23:26, 0] = self.pqr_cmd
-        istate = np.array([[self.trajectory_index], [self.inner_step], [0]], dtype=np.int32)
-        offs = np.array([0, len(traj)], dtype=np.int64)
-        ctx().call("uavac_controller_tick", C.byref(V), nat.np_ptr(traj), nat.np_ptr(offs), nat.np_ptr(state),
-                   nat.np_ptr(istate), 1)
-        q.omega = state[13:17, 0].copy()
-        q.omega_command = state[17:21, 0].copy()
-        self.controller.integral_error = state[21, 0]
-        self.thrust_cmd = state[22, 0]
-        self.pqr_cmd = state[23:26, 0].copy()
-        self.trajectory_index = int(istate[0, 0])
-        self.inner_step = int(istate[1, 0])
+        p = self._pilot()
+        st, ist = p.state[:, 0], p.istate[:, 0]
+        st[0:13] = q.X
+        st[13:17] = q.omega
+        st[17:21] = q.omega_command
+        st[21] = self.controller.integral_error
+        st[22] = self.thrust_cmd
+        st[23:26] = self.pqr_cmd
+        ist[0], ist[1] = self.trajectory_index, self.inner_step
+        p.tick(V, nat.PILOT_CONTROLLER)
+        q.omega = st[13:17].copy()
+        q.omega_command = st[17:21].copy()
+        self.controller.integral_error = float(st[21])
+        self.thrust_cmd = float(st[22])
+        self.pqr_cmd = st[23:26].copy()
+        self.trajectory_index = int(ist[0])
+        self.inner_step = int(ist[1])
 
 
 class FreeFlightSimulation:
@@ -69,19 +78,21 @@ class FreeFlightSimulation:
         self.quad = quad
         self.obstacles = None if obstacles is None else nat.as_f64(obstacles).reshape(-1, 6)
         self.collision_detected = False
+        self._pilot = None
 
     def step(self) -> np.ndarray:
         q = self.quad
         V = vehicle_from(q)
-        state = np.zeros((nat.STATE_ROWS, 1))
-        state[0:13, 0] = q.X
-        state[13:17, 0] = q.omega
-        istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
-        n_obs = 0 if self.obstacles is None else len(self.obstacles)
-        ctx().call("uavac_dynamics_step", C.byref(V), nat.np_ptr(state), nat.np_ptr(istate), 1,
-                   nat.np_ptr(self.obstacles), n_obs)
-        q.X = state[0:13, 0].copy()
-        self.collision_detected = self.collision_detected or bool(istate[2, 0])
+        if self._pilot is None:
+            self._pilot = nat.Pilot(ctx(), np.zeros((1, nat.TRAJ_COLS)), np.array([0, 1], dtype=np.int64))
+            self._pilot.set_obstacles(self.obstacles)
+        st, ist = self._pilot.state[:, 0], self._pilot.istate[:, 0]
+        st[0:13] = q.X
+        st[13:17] = q.omega
+        ist[2] = 0
+        self._pilot.tick(V, nat.PILOT_DYNAMICS)
+        q.X = st[0:13].copy()
+        self.collision_detected = self.collision_detected or bool(ist[2])
         return q.X.copy()
 
 

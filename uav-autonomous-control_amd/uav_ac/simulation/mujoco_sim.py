@@ -182,18 +182,19 @@ class MujocoSimulation:
         return self._collision_detected
 
     def step(self) -> np.ndarray:
-        """One inner-loop time step from the current rotor speeds (reference mujoco_sim.py:144-151)."""
+        """One inner-loop time step from the current rotor speeds (reference mujoco_sim.py:144-151): `uavac_pilot_tick`
+        (vehicle half) on state in pinned memory the kernel updates in place; the obstacle list is resident."""
         q = self.quad
-        state = np.zeros((nat.STATE_ROWS, 1))
-        state[0:13, 0] = q.X
-        state[13:17, 0] = q.omega
-        istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
-        istate[3, 0] = self._ground_bits
-        n_obs = len(self.obstacles)
-        ctx().call("uavac_dynamics_step", C.byref(self.vehicle()), nat.np_ptr(state), nat.np_ptr(istate), 1,
-                   nat.np_ptr(self.obstacles) if n_obs else None, n_obs)
-        q.X = state[0:13, 0].copy()
-        self._ground_bits = int(istate[3, 0])
-        self._collision_detected = (self._collision_detected or bool(istate[2, 0]) or
+        if getattr(self, "_pilot", None) is None:
+            self._pilot = nat.Pilot(ctx(), np.zeros((1, nat.TRAJ_COLS)), np.array([0, 1], dtype=np.int64))
+            self._pilot.set_obstacles(self.obstacles if len(self.obstacles) else None)
+        st, ist = self._pilot.state[:, 0], self._pilot.istate[:, 0]
+        st[0:13] = q.X
+        st[13:17] = q.omega
+        ist[2], ist[3] = 0, self._ground_bits
+        self._pilot.tick(self.vehicle(), nat.PILOT_DYNAMICS)
+        q.X = st[0:13].copy()
+        self._ground_bits = int(ist[3])
+        self._collision_detected = (self._collision_detected or bool(ist[2]) or
                                     bool(self._ground_bits & nat.GROUND_HIT_AFTER_TAKEOFF))
         return q.X.copy()
