@@ -106,8 +106,9 @@ const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
 /* Tuning knobs; results never depend on them (tested bit for bit).  "rollout_align": 1 (default) =
  * precede a rollout launch that writes a log by an empty kernel of the same workgroup shape (one
  * compute + one store wave), which makes the hardware place one wave of each kind on every SIMD
- * whatever ran before; 0 = do not.  Default from the environment
- * (UAVAC_ROLLOUT_ALIGN) at uavac_create. */
+ * whatever ran before; 0 = do not.  "yaw_group": 1, 4, 8 (default) or 16 = how
+ * many 64-row chunks of the sampler's dense yaw column are written together.  Defaults from the
+ * environment (UAVAC_ROLLOUT_ALIGN, UAVAC_YAW_GROUP) at uavac_create. */
 int uavac_set_option(uavac_ctx *ctx, const char *name, int value);
 /* The _dev planning entry points report data-dependent failures through sticky device-side flags
  * instead of synchronising: flags[0] non-finite segment duration, flags[1] singular knot system,

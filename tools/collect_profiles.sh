@@ -1,0 +1,41 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, collected on the GPU box into gpurun_out/profiles_<tag>/ (copy what is to be
+# judged into profiles/ afterwards).   bash tools/collect_profiles.sh r02
+set -u
+TAG=${1:-r02}
+cd "${GRAFT_REPO_ROOT:-.}"
+OUT=gpurun_out/profiles_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+export TMPDIR=/tmp
+bash tools/box_mode.sh 2>&1 | grep -E "Unique|sampler" | head -2 > "$OUT/box.txt"
+# 1. kernel trace + stats of the bench command (HIP-event average in the JSON line must agree with the trace average)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config4 > "$OUT/${TAG}_bench_profiled.json" 2> "$OUT/trace.err"
+python3 tools/summarize_trace.py "$(ls $OUT/trace/*kernel_trace.csv | head -1)" "$OUT/${TAG}_bench" > "$OUT/per_dispatch_summary.txt"
+# 2. PMC traffic (three passes) -> hbm_traffic.json + pmc summary
+python3 tools/pmc_traffic.py > "$OUT/pmc_traffic.log" 2>&1
+cp gpurun_out/hbm_traffic.json "$OUT/hbm_traffic.json"; cp gpurun_out/r02_pmc_summary.csv "$OUT/${TAG}_pmc_summary.csv"
+cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json      # so that the bench of step 3 quotes it
+# 3. the plain bench line (what the driver runs)
+python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
+# 4. other BASELINE configurations
+python3 tools/config_sweep.py > "$OUT/${TAG}_config_sweep.jsonl" 2>/dev/null
+# 5. small batch: where the cycles go
+python3 tools/small_batch_profile.py 2>/dev/null | tail -1 > "$OUT/${TAG}_small_batch.json"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pmc_small" -o pmc -- python3 tools/small_batch_profile.py > /dev/null 2>&1
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, glob, collections, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+f = glob.glob(out + "/pmc_small/**/*counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    if "control_rollout" in r["Kernel_Name"]:
+        acc[r["Kernel_Name"].split("<")[1].split(">")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+json.dump({k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in acc.items()}, open(f"{out}/{tag}_small_batch_pmc.json", "w"), indent=1)
+PY
+# 6. issue / exchange micro-probes and the host-facing paths
+./tools/dpp_exchange_probe.bin > "$OUT/${TAG}_dpp_exchange_probe.txt" 2>&1
+python3 tools/single_uav_loop.py 2>/dev/null | tail -4 > "$OUT/${TAG}_single_uav_loop.txt"
+python3 tools/host_path_rate.py 2>/dev/null | tail -2 > "$OUT/${TAG}_host_path_rate.txt"
+python3 tools/first_launch_bisect.py 2>/dev/null | grep "^|" > "$OUT/${TAG}_first_launch_bisect.md"
+rm -rf "$OUT/trace/"*results.db "$OUT/pmc_small"
+ls -la "$OUT"

@@ -20,7 +20,7 @@ for name, B, m, K, aabb in (("config2", 4096, 8, 10000, None), ("config3", 65536
     plan = eng.plan(missions(B, m, 0, B), 3.0, 0.01)
     fleet = eng.fleet(plan)
     log = torch.empty((1000, 13, B), dtype=torch.float64, device="cuda:0")
-    tp = t(lambda: (eng.solve(plan), eng.sample(plan)))
+    tp = t(lambda: eng.replan(plan))
     def roll():
         fleet.reset()
         for _ in range(K // 1000): fleet.rollout(1000, state_log=log, aabbs=aabb)

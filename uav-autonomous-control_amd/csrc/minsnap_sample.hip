@@ -18,8 +18,6 @@
 namespace {
 
 constexpr int SB = 64;                  // rows per chunk == threads per workgroup == one wavefront
-constexpr int kYawGroup = 4;            // chunks whose yaws leave together
-constexpr double kMinSpeedForYaw = 1e-3;   // MinimumSnap.MIN_HORIZONTAL_SPEED_FOR_YAW, minimum_snap.py:11
 constexpr double kPi = 3.141592653589793238462643383279502884;
 constexpr double kTwoPi = 2.0 * kPi;
 
@@ -30,13 +28,15 @@ __device__ __forceinline__ double floored_mod(double a, double b) {
     return r;
 }
 
-// np.unwrap's per-step correction for dd = p[i] - p[i-1]
+// np.unwrap's per-step correction for dd = p[i] - p[i-1]:
+//     ddmod = mod(dd + pi, 2 pi) - pi ; ddmod[(ddmod == -pi) & (dd > 0)] = pi ; corr = ddmod - dd ; corr[|dd| < pi] = 0
+// Headings of consecutive samples rarely jump by pi or more, and NumPy discards the modulo's result whenever they do
+// not: the (long) fp64 fmod runs only for the lanes that need it, i.e. for almost no wave.
 __device__ __forceinline__ double unwrap_correction(double dd) {
+    if (fabs(dd) < kPi) return 0.0;
     double ddmod = floored_mod(dd + kPi, kTwoPi) - kPi;
     if (ddmod == -kPi && dd > 0.0) ddmod = kPi;
-    double corr = ddmod - dd;
-    if (fabs(dd) < kPi) corr = 0.0;
-    return corr;
+    return ddmod - dd;
 }
 
 // double held by lane `l` (wave-uniform index): two v_readlane instead of two LDS-pipe bpermutes
@@ -51,9 +51,13 @@ __device__ __forceinline__ int segment_of(const int *__restrict__ pre, int m, in
 }
 
 // |v_xy| >= MIN_HORIZONTAL_SPEED_FOR_YAW as NumPy evaluates it (np.linalg.norm(..., axis=1) = sqrt(add.reduce(x * x)):
-// two rounded products, one rounded sum -- no fused multiply-add)
+// two rounded products, one rounded sum -- no fused multiply-add), without the square root: sqrt is correctly rounded and
+// monotonic, so sqrt(s) >= 1e-3 holds exactly for s >= s*, s* the smallest double whose root rounds to >= 1e-3.  That is
+// 0x1.0c6f7a0b5ed8dp-20 (= the double nearest 1e-6; its predecessor's root is below 1e-3 -- checked with exact
+// rationals against ((1e-3 + pred(1e-3)) / 2)^2).  Infinities pass and NaNs fail either way.
+constexpr double kMinSpeedSquared = 0x1.0c6f7a0b5ed8dp-20;
 __device__ __forceinline__ bool has_heading(double vx, double vy) {
-    return sqrt(__dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy))) >= kMinSpeedForYaw;
+    return __dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy)) >= kMinSpeedSquared;
 }
 
 // State of _calculate_yaws carried from one 64-row chunk to the next (wave-uniform): has a usable heading been seen,
@@ -101,7 +105,8 @@ __device__ __forceinline__ double yaw_chunk(bool valid, double ang, int lane, Ya
 // DERIVS: also write jerk / snap, [N][3] each -- the two outputs the reference computes in comments only
 // (minimum_snap.py:111-112,118-119: polynom(8, 3 | 4, t) @ coeffs); separate arrays, never extra row columns.
 // capacity_rows >= 0: the row buffer holds that many rows; a plan that needs more is refused as a whole (flag 2).
-template <bool HITS, bool DERIVS>
+// YG: chunks whose dense-column yaws leave together (LDS buffer of YG * 64 doubles per wave).
+template <bool HITS, bool DERIVS, int kYawGroup>
 __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__restrict__ coeffs,
                                                            const int32_t *__restrict__ seg_rows,
                                                            const int64_t *__restrict__ row_offsets, int B, int m,
@@ -191,7 +196,18 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             if (last_of_group) {
                 lds_wave_fence();
                 const int n_group = min(N, c0 + SB) - g0;
-                for (int i = lane; i < n_group; i += SB) yaw_dense[row0 + g0 + i] = ybuf[i];
+                // 16-byte stores from an even element (like the rows below); at most one 8-byte head and tail
+                double *yd = yaw_dense + row0 + g0;
+                const int yh = (int)((reinterpret_cast<uintptr_t>(yd) >> 3) & 1);
+                if (yh && lane == 0) yd[0] = ybuf[0];
+                const int ypairs = (n_group - yh) >> 1;
+                for (int p = lane; p < ypairs; p += SB) {
+                    double2 v;
+                    v.x = ybuf[yh + 2 * p];
+                    v.y = ybuf[yh + 2 * p + 1];
+                    *reinterpret_cast<double2 *>(yd + yh + 2 * p) = v;
+                }
+                if (((n_group - yh) & 1) && lane == 63) yd[n_group - 1] = ybuf[n_group - 1];
             }
         }
         if (active) {
@@ -254,15 +270,23 @@ int uavac_launch_yaw_scan(uavac_ctx *ctx, const double *velocities, const int64_
 
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
                         int B, int m, double dt, double *traj, const SampleExtras &x) {
+    const bool plain = !(x.aabb && x.hit) && !(x.jerk || x.snap);
+    // Dense yaw column: 8 chunks (4 KB) leave together.  Measured for the bench's plan on a typical box of the pool, rows +
+    // column / rows only: 1 chunk 1.84 / 1.52 ms, 4 chunks 1.77, 8 chunks 1.66, 16 chunks 1.68 (LDS then costs occupancy).
+    const int yg = (plain && (ctx->yaw_group == 1 || ctx->yaw_group == 4 || ctx->yaw_group == 16)) ? ctx->yaw_group : 8;
     size_t lds = sizeof(double) * ((size_t)SB * UAVAC_TRAJ_COLS + (size_t)24 * m) + sizeof(int) * (size_t)((m + 2 + 1) & ~1) +
-                 (x.yaw_dense ? sizeof(double) * kYawGroup * SB : 0);
+                 (x.yaw_dense ? sizeof(double) * yg * SB : 0);
     const bool hits = x.aabb && x.hit, derivs = x.jerk || x.snap;
     if (hits) UAVAC_HIP(ctx, hipMemsetAsync(x.hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
-#define UAVAC_SAMPLE(H, D)                                                                                             \
-    hipLaunchKernelGGL((minsnap_sample_kernel<H, D>), dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows, row_offsets, \
+#define UAVAC_SAMPLE(H, D, Y)                                                                                          \
+    hipLaunchKernelGGL((minsnap_sample_kernel<H, D, Y>), dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows, row_offsets, \
                        B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags)
-    if (hits) { if (derivs) UAVAC_SAMPLE(true, true); else UAVAC_SAMPLE(true, false); }
-    else      { if (derivs) UAVAC_SAMPLE(false, true); else UAVAC_SAMPLE(false, false); }
+    if (hits) { if (derivs) UAVAC_SAMPLE(true, true, 8); else UAVAC_SAMPLE(true, false, 8); }
+    else if (derivs) UAVAC_SAMPLE(false, true, 8);
+    else if (yg == 1) UAVAC_SAMPLE(false, false, 1);
+    else if (yg == 4) UAVAC_SAMPLE(false, false, 4);
+    else if (yg == 16) UAVAC_SAMPLE(false, false, 16);
+    else UAVAC_SAMPLE(false, false, 8);
 #undef UAVAC_SAMPLE
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;

@@ -233,6 +233,7 @@ int uavac_create(uavac_ctx **out, int device_id) {
         delete ctx;
         return UAVAC_EHIP;
     }
+    if (const char *e = getenv("UAVAC_YAW_GROUP")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 16) ctx->yaw_group = v; }
     if (const char *e = getenv("UAVAC_ROLLOUT_ALIGN")) ctx->rollout_align = (e[0] == '0') ? 0 : 1;
     *out = ctx;
     return UAVAC_OK;
@@ -278,7 +279,10 @@ int uavac_device(const uavac_ctx *ctx) { return ctx ? ctx->device : UAVAC_EINVAL
 int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return UAVAC_EINVAL;
     const std::string n(name);
-    if (n == "rollout_align") {
+    if (n == "yaw_group") {
+        if (value != 1 && value != 4 && value != 8 && value != 16) return uavac_fail(ctx, UAVAC_EINVAL, "yaw_group is 1, 4, 8 or 16");
+        ctx->yaw_group = value;
+    } else if (n == "rollout_align") {
         ctx->rollout_align = value ? 1 : 0;
     } else {
         return uavac_fail(ctx, UAVAC_EINVAL, "unknown option");

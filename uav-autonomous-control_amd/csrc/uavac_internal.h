@@ -28,6 +28,7 @@ struct uavac_ctx {
     size_t pin_cap = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::string err;
+    int yaw_group = 8;               // tuning: chunks of the sampler's dense yaw column that leave together (1, 4, 8, 16)
     int rollout_align = 1;           // tuning: launch the 2-wave aligner kernel before a logged launch of shape 1
     std::string last_rollout;        // name and template arguments of the rollout kernel launched last (diagnostics)
 };
