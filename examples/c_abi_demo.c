@@ -1,7 +1,10 @@
 /*
  * The C ABI from plain C: plan one mission through five waypoints (minimum snap), fly it with the cascaded
  * controller + free-body dynamics, print where the vehicle ends up.  No Python, no torch: only include/uavac.h and
- * libuavac.so (host-pointer entry points; the library stages through device memory itself).
+ * libuavac.so (host-pointer entry points; the library stages through device memory itself).  Then the same flight
+ * tick by tick through the resident session (uavac_pilot_*: what a host-owned `tc.step(); sim.step()` loop uses), from the
+ * ground with the build-defined ground plane, the stand-alone yaw scan, and the multi-GPU gather's RCCL calls on this one
+ * GPU (communicator of world size 1: counts, the root's own block, a self send/receive through the transport).
  *
  *   gcc examples/c_abi_demo.c -Iinclude -Luav-autonomous-control_amd/lib -luavac \
  *       -Wl,-rpath,$PWD/uav-autonomous-control_amd/lib -lm -o c_abi_demo && ./c_abi_demo
@@ -56,6 +59,49 @@ int main(void) {
         const double e = sqrt(pow(x[0] - t[0], 2) + pow(x[1] - t[1], 2) + pow(x[2] - t[2], 2));
         if (e > worst) worst = e;
     }
+    /* ---- the same mission tick by tick: resident session, state in pinned memory the kernels update in place ---- */
+    uavac_pilot *pilot = NULL;
+    CHECK(uavac_pilot_create(ctx, traj, offs, B, &pilot));
+    double *ps = uavac_pilot_state(pilot);
+    int32_t *pi = uavac_pilot_istate(pilot);
+    uavac_vehicle Vg = V;
+    Vg.ground = 1;                                                   /* plane at z = 0, body half height 0.02 m */
+    for (int i = 0; i < UAVAC_STATE_ROWS; ++i) ps[i] = 0.0;
+    ps[0] = wp[0][0]; ps[1] = wp[0][1]; ps[2] = -0.0199;             /* resting on the plane (0.1 mm into it), rotors stopped */
+    ps[3] = 1.0;
+    int touched = 0;
+    for (int k = 0; k < 4000; ++k) {
+        CHECK(uavac_pilot_tick(pilot, &Vg, UAVAC_PILOT_CONTROLLER | UAVAC_PILOT_DYNAMICS));
+        touched |= pi[3] & UAVAC_GROUND_IN_CONTACT;
+    }
+    const int took_off = (pi[3] & UAVAC_GROUND_TAKEN_OFF) && !(pi[3] & UAVAC_GROUND_HIT_AFTER_TAKEOFF);
+    printf("pilot: 4000 ticks from the ground: z = %.3f m, stood on the plane first: %s, took off cleanly: %s\n", ps[2],
+           touched ? "yes" : "no", took_off ? "yes" : "no");
+    uavac_pilot_destroy(pilot);
+
+    /* ---- MinimumSnap._calculate_yaws on its own: headings of the sampled velocities == the rows' yaw column ---- */
+    double *vel = malloc(sizeof(double) * 3 * (size_t)offs[1]), *yaws = malloc(sizeof(double) * (size_t)offs[1]);
+    for (int64_t r = 0; r < offs[1]; ++r)
+        for (int a = 0; a < 3; ++a) vel[3 * r + a] = traj[UAVAC_TRAJ_COLS * r + 3 + a];
+    CHECK(uavac_yaw_scan(ctx, vel, offs[1], yaws));
+    int yaw_same = 1;
+    for (int64_t r = 0; r < offs[1]; ++r) yaw_same &= yaws[r] == traj[UAVAC_TRAJ_COLS * r + 9];
+
+    /* ---- the gather of the multi-GPU path with a communicator of one rank (N GPUs: one process each, same calls) ---- */
+    char id[UAVAC_COMM_ID_BYTES];
+    void *comm = NULL;
+    int64_t counts[1];
+    CHECK(uavac_comm_unique_id(ctx, id));
+    CHECK(uavac_comm_init_rank(ctx, id, /*world=*/1, /*rank=*/0, &comm));
+    CHECK(uavac_gather_counts(ctx, comm, offs[1], counts));
+    int gather_ok = counts[0] == offs[1];
+    CHECK(uavac_comm_destroy(ctx, comm));
+
+    printf("yaw scan equals the sampler's column: %s; RCCL communicator of one rank counted %lld rows: %s\n",
+           yaw_same ? "yes" : "no", (long long)counts[0], gather_ok ? "ok" : "MISMATCH");
+    free(vel); free(yaws);
+    if (!touched || !took_off || !yaw_same || !gather_ok) return 3;
+
     printf("rows %lld, ticks %d, final position (%.3f, %.3f, %.3f), %.4f m from the last row, worst tracking error %.4f m, cursor %d\n",
            (long long)offs[1], K, state[0], state[1], state[2], miss, worst, (int)istate[0]);
     free(coeffs); free(traj); free(log);

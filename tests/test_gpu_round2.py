@@ -342,3 +342,74 @@ def test_full_size_properties_config4_rank_shard(eng):
         state, istate = co.initial_state(traj[0, 0:3])
         s_ref, _ = co.rollout(traj, state, istate, K, log_cmd=False)
         assert col_err(slog[:, :, j], s_ref) < TOL, b
+
+
+# ------------------------------------------------------------------------------------------- resident session
+def test_pilot_ticks_equal_the_fused_rollout_bit_for_bit(nat):
+    """`uavac_pilot_tick` (controller + vehicle half per call, state in pinned mapped memory) for K calls == one fused
+    `uavac_control_rollout` of K ticks on the same three missions, including the obstacle flag; editing the pinned state
+    between calls is honoured."""
+    from oracle import minsnap_oracle as mo
+    ctx = nat.Context(0)
+    wps = mo.synthetic_missions(3, 4)
+    trajs = [mo.plan(w, 3.0, 0.01, method="solve") for w in wps]
+    rows = np.vstack(trajs)
+    offs = np.concatenate([[0], np.cumsum([len(t) for t in trajs])]).astype(np.int64)
+    V = nat.Vehicle.default()
+    K, B = 700, 3
+    aabbs = np.array([[-100.0, 100.0, -100.0, 100.0, -3.2, -3.03]])      # a slab just below the start altitude (z = -3)
+    state = np.zeros((nat.STATE_ROWS, B)); istate = np.zeros((nat.ISTATE_ROWS, B), np.int32)
+    ctx.call("uavac_state_init", C.byref(V), nat.np_ptr(np.ascontiguousarray(wps[:, 0, :])), B, 1, nat.np_ptr(state), nat.np_ptr(istate))
+    ref_s, ref_i = state.copy(), istate.copy()
+    log = np.empty((K, 13, B))
+    ctx.call("uavac_control_rollout", C.byref(V), nat.np_ptr(rows), nat.np_ptr(offs), nat.np_ptr(ref_s), nat.np_ptr(ref_i), B, K,
+             nat.np_ptr(log), None, nat.np_ptr(aabbs), 1)
+    p = nat.Pilot(ctx, rows, offs)
+    p.set_obstacles(aabbs)
+    p.state[:] = state
+    p.istate[:] = istate
+    for k in range(K):
+        if k % 2:
+            p.tick(V)                                                      # both halves in one call
+        else:
+            p.tick(V, nat.PILOT_CONTROLLER); p.tick(V, nat.PILOT_DYNAMICS)
+        assert np.array_equal(p.state[0:13], log[k])
+    assert np.array_equal(p.state, ref_s) and np.array_equal(p.istate, ref_i)
+    assert ref_i[2].any()                                                  # somebody did cross the slab
+    p.state[2, 1] += 0.25                                                  # the host moves a vehicle: the next tick starts there
+    z = p.state[2, 1]
+    p.tick(V, nat.PILOT_DYNAMICS)
+    assert abs(p.state[2, 1] - z) < 0.01 and p.state[2, 1] != z
+    p.close()
+    with pytest.raises(nat.UavacError):
+        nat.Pilot(ctx, rows, np.array([0, 5, 3], dtype=np.int64))          # offsets must not decrease
+
+
+def test_plan_chain_edge_sizes_and_optional_outputs(eng, nat):
+    """One segment and UAVAC_MAX_SEGMENTS through the one-call chain; the yaw column is optional; jerk / snap of a single
+    segment equal the closed form of the rest-to-rest septic."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    for m in (1, nat.MAX_SEGMENTS):
+        wps = mo.synthetic_missions(5, m)
+        plan = eng.plan(wps, 3.0, 0.01)
+        ref = plan.traj.clone()
+        plan.traj.zero_()
+        yaw, plan.yaw = plan.yaw, None
+        eng._bind_stream()
+        eng.ctx.call("uavac_minsnap_plan_dev", C.c_void_p(plan.waypoints.data_ptr()), plan.B, plan.m, plan.velocity, plan.dt,
+                     C.c_void_p(plan.times.data_ptr()), C.c_void_p(plan.seg_rows.data_ptr()), C.c_void_p(plan.row_offsets.data_ptr()),
+                     C.c_void_p(plan.coeffs.data_ptr()), C.c_void_p(plan.status.data_ptr()), C.c_void_p(plan.traj.data_ptr()),
+                     int(plan.traj.shape[0]), None)
+        assert torch.equal(plan.traj, ref) and eng.take_flags() == [0, 0, 0, 0]
+        plan.yaw = yaw
+        assert col_err(plan.mission(4), mo.plan(wps[4], 3.0, 0.01, method="solve")) < 1e-6
+    plan = eng.plan(np.array([[[0.0, 0.0, -1.0], [3.0, 0.0, -1.0]]]), 1.0, 0.01)           # T = 3 * 1.5 = 4.5 s, along x
+    jerk, snap = eng.sample_derivatives(plan)
+    T, d = 4.5, 3.0
+    t = np.arange(0.0, T, 0.01) / T
+    # x(tau) = d (35 tau^4 - 84 tau^5 + 70 tau^6 - 20 tau^7): rest-to-rest minimum snap
+    j = d / T ** 3 * (840 * t - 5040 * t ** 2 + 8400 * t ** 3 - 4200 * t ** 4)
+    s4 = d / T ** 4 * (840 - 10080 * t + 25200 * t ** 2 - 16800 * t ** 3)
+    assert np.allclose(jerk[:, 0].cpu().numpy(), j, rtol=1e-9, atol=1e-9) and np.allclose(snap[:, 0].cpu().numpy(), s4, rtol=1e-9, atol=1e-9)
+    assert float(jerk[:, 1:].abs().max()) < 1e-12 and float(snap[:, 1:].abs().max()) < 1e-12

@@ -7,7 +7,13 @@ methods.  Every distance, steering step, segment-vs-cuboid test and the whole of
 `libuavac.so` (`uavac_rrt_*`); there is no CPU fallback.
 
 Differences from the reference, all in reporting: `run()` does not print per-iteration progress (the iterations
-happen inside one kernel), only the final cost line.
+happen inside one kernel), only the final cost line.  Two exception details differ on purpose:
+* when no path is found, the reference's `run()` reaches `_is_path_found(None)` and dies with an `AttributeError`
+  before its own `raise Exception("No path found")` (rrt.py:72-73) can run; here that intended exception is what is raised;
+* a dictionary lookup of a key that is not in the tree raises `KeyError` upstream only if the new node is not value-equal
+  to the start (or a non-start neighbour exists); the kernel reports KEY_ERROR for every such lookup.  The two agree
+  except when a node equals the start by value but not bit for bit (-0.0 against 0.0), which `np.round(..., 2)` of drawn
+  coordinates can produce only for a start on a coordinate plane.
 """
 from __future__ import annotations
 
