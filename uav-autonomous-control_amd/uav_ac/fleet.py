@@ -607,11 +607,18 @@ class RcclComm:
         return dst
 
     def close(self, abort: bool = False):
-        if self._h.value:
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and self.engine.ctx._h.value:
             try:
-                self.engine.ctx.call("uavac_comm_abort" if abort else "uavac_comm_destroy", self._h)
+                self.engine.ctx.call("uavac_comm_abort" if abort else "uavac_comm_destroy", h)
             finally:
                 self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                # pragma: no cover - interpreter shutdown
+            pass
 
 
 def gather_rows(rows, dst: int = 0, group=None, max_message_bytes: int = 1 << 30, comm: "RcclComm" = None):
