@@ -7,7 +7,7 @@
 """
 import csv
 import sys
-from collections import OrderedDict, defaultdict
+from collections import OrderedDict
 
 
 def short(name):
@@ -36,29 +36,34 @@ def main(path, prefix):
         for (k, g, wg), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k, g, wg, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 4), min(v), max(v)])
     # per-dispatch table: steps are delimited by the row-count kernel of the planning chain
+    # (a step that starts after the GPU has idled -- process start, a host synchronisation -- runs its first launches at
+    # ramping clocks: it is listed with the idle time in front of it and left out of the means)
+    WINDOW = 20e6                                  # ns: how busy was the GPU in the 20 ms before the step?
+    spans = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
     steps, cur = [], None
-    for r in rows:
+    for i, r in enumerate(rows):
         k = short(r["Kernel_Name"])
         if k.startswith("row_counts_kernel"):
-            cur = []
+            t0 = spans[i][0]
+            busy = sum(min(e, t0) - max(s, t0 - WINDOW) for s, e in spans[:i] if e > t0 - WINDOW)
+            cur = {"idle_ms": (WINDOW - busy) / 1e6, "us": []}
             steps.append(cur)
         elif k.startswith("control_rollout_kernel") and cur is not None and int(r["Grid_Size_X"]) >= 65536:
-            cur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    full = [s for s in steps if len(s) == 10]
+            cur["us"].append((spans[i][1] - spans[i][0]) / 1e3)
+    full = [s for s in steps if len(s["us"]) == 10]
+    steady = [s for s in full if s["idle_ms"] < 2.0]
     with open(prefix + "_per_dispatch.csv", "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["step"] + [f"launch_{i + 1}_us" for i in range(10)])
+        w.writerow(["step", "gpu_idle_ms_in_the_20_ms_before"] + [f"launch_{i + 1}_us" for i in range(10)])
         for i, s in enumerate(full):
-            w.writerow([i] + [round(x, 1) for x in s])
-        if full:
-            w.writerow(["mean"] + [round(sum(s[j] for s in full) / len(full), 1) for j in range(10)])
-    by_pos = defaultdict(list)
-    for s in full:
-        for j, x in enumerate(s):
-            by_pos[j].append(x)
-    if full:
-        means = [sum(by_pos[j]) / len(by_pos[j]) for j in range(10)]
-        print("rollout launch position means (us):", [round(m, 1) for m in means], "spread %.1f %%" % (100 * (max(means) / min(means) - 1)))
+            w.writerow([i, round(s["idle_ms"], 2)] + [round(x, 1) for x in s["us"]])
+        if steady:
+            w.writerow(["mean of steps that follow a busy GPU (< 2 ms idle)", ""] +
+                       [round(sum(s["us"][j] for s in steady) / len(steady), 1) for j in range(10)])
+    if steady:
+        means = [sum(s["us"][j] for s in steady) / len(steady) for j in range(10)]
+        print(f"rollout launch position means over {len(steady)} back-to-back steps (us):", [round(m, 1) for m in means],
+              "spread %.1f %%" % (100 * (max(means) / min(means) - 1)))
 
 
 if __name__ == "__main__":
