@@ -68,6 +68,15 @@ __device__ __forceinline__ double row_col(const RowRegs &r, int c) {      // c i
     return __builtin_bit_cast(double, h);
 }
 
+// A store whose address is a wave-uniform 64-bit base in SGPRs plus a 32-bit byte offset per lane.  The store wave issues
+// 13 (+12) of these per tick; with the lane folded into a 64-bit VGPR pointer every one of them needed a 64-bit vector
+// add first, and those adds queue behind the compute wave's fp64 instructions on the SIMD's single vector issue port
+// (each waits up to one fp64 instruction, ~7 cycles).  In this form the row addresses advance with scalar adds and the
+// store wave issues no vector-ALU instruction per store.
+__device__ __forceinline__ void store_uniform_base(double *base, unsigned lane_bytes, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane_bytes), "v"(v), "s"(base) : "memory");
+}
+
 // The constants only the outer loop needs (gains, flight limits) are re-read from the kernel-argument
 // segment inside the outer block instead of living in SGPRs across the whole tick loop: the per-tick path
 // alone needs ~50 SGPRs of constants, both sets together overflow the 102 available and the overflow
@@ -120,6 +129,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         const int lane = (threadIdx.x & 63) + ((threadIdx.x - NU) >> 6) * (QPL * 64);
         __builtin_amdgcn_s_setprio(3);            // few instructions, all on the critical store stream: issue first
         const bool full = col0 + NU <= B;          // every column of this workgroup exists: no per-store mask
+        const unsigned lane_bytes = (unsigned)lane * 8u;
         // With a state log the per-tick obstacle test runs HERE, on the positions this wave is about to store, after
         // its stores have been issued: the compute wave's tick stays as short as without obstacles (the two stages
         // couple through one barrier per tick; lengthening the compute stage to the length of the store stage cost
@@ -138,12 +148,13 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 for (int r = 0; r < 13; ++r)
 #pragma unroll
                     for (int q = 0; q < QPL; ++q) v[r][q] = src[r * NU + q * 64];
-                double *dst = state_log + (size_t)k * 13 * sB + col0 + lane;
+                double *dst = state_log + (size_t)k * 13 * sB + col0;               // wave-uniform: lives in SGPRs
 #pragma unroll
                 for (int r = 0; r < 13; ++r)
 #pragma unroll
                     for (int q = 0; q < QPL; ++q)
-                        if (full || col0 + q * 64 + lane < B) dst[r * sB + q * 64] = v[r][q];      // 512-B coalesced wave store
+                        if (full || col0 + q * 64 + lane < B)                       // 512-B coalesced wave store
+                            store_uniform_base(dst + r * sB + q * 64, lane_bytes, v[r][q]);
                 if (AABB_HERE) {
                     const double x = v[0][0], y = v[1][0], z = v[2][0];
                     for (int o = 0; o < n_obs; ++o) {
@@ -160,12 +171,12 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 for (int r = 0; r < UAVAC_CMD_COLS; ++r)
 #pragma unroll
                     for (int q = 0; q < QPL; ++q) v[r][q] = src[(CMD0 + r) * NU + q * 64];
-                double *dst = cmd_log + (size_t)k * UAVAC_CMD_COLS * sB + col0 + lane;
+                double *dst = cmd_log + (size_t)k * UAVAC_CMD_COLS * sB + col0;
 #pragma unroll
                 for (int r = 0; r < UAVAC_CMD_COLS; ++r)
 #pragma unroll
                     for (int q = 0; q < QPL; ++q)
-                        if (full || col0 + q * 64 + lane < B) dst[r * sB + q * 64] = v[r][q];
+                        if (full || col0 + q * 64 + lane < B) store_uniform_base(dst + r * sB + q * 64, lane_bytes, v[r][q]);
             }
         }
         if (AABB_HERE && mine) istate[2 * sB + col0 + lane] = coll;
