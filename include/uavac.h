@@ -41,7 +41,7 @@ extern "C" {
 
 #define UAVAC_MAX_SEGMENTS 64   /* m, segments per mission                          */
 #define UAVAC_TRAJ_COLS 11      /* x y z vx vy vz ax ay az yaw spline_id: minimum_snap.py:122-123 */
-#define UAVAC_STATE_ROWS 26     /* see uavac_control_* below                        */
+#define UAVAC_STATE_ROWS 30     /* see uavac_control_* below                        */
 #define UAVAC_ISTATE_ROWS 4
 #define UAVAC_CMD_COLS 12
 
@@ -158,22 +158,26 @@ int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const do
                                   const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                                   double dt, double *traj, const double *aabb, int32_t *hit);
 
-/* The sampler with every optional output: yaw [rows] (or NULL) as above; jerk / snap [rows][3] (or
+/* The sampler with every optional output: yaw [rows] (or NULL) as above; first_yaw [B] (or NULL) =
+ * the heading of each mission's first row that has one (what the rows before it take; 0 when no
+ * row has one) -- all a plan-fed rollout needs to scan the yaw itself; jerk / snap [rows][3] (or
  * NULL) = polynom(8, 3, t) @ coeffs and polynom(8, 4, t) @ coeffs, the two samples the reference
  * evaluates in comments only (minimum_snap.py:111-112,118-119).  They are separate arrays: the
  * (N, 11) row layout of get_trajectory() never changes. */
 int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows,
                                     const int64_t *row_offsets, int B, int m, double dt, double *traj,
-                                    double *yaw, double *jerk, double *snap);
+                                    double *yaw, double *first_yaw, double *jerk, double *snap);
 /* The whole planning chain of MinimumSnap.get_trajectory() (obstacles=None; minimum_snap.py:59-61,
  * 97-124) enqueued by ONE call: times + row counts, row offsets, coefficient solve, sampler (+ yaw
- * column when yaw != NULL) -- four kernel launches back to back, no host code in between.  The row
+ * column when yaw != NULL, + the missions' first headings when first_yaw != NULL) -- four kernel
+ * launches back to back, no host code in between.  The row
  * buffer must have been sized by the caller: traj holds traj_capacity_rows rows (yaw as many
  * values); when the plan needs more, nothing is written and flag 2 is raised (uavac_take_flags).
  * Typical use: size the buffers once with uavac_minsnap_row_counts_dev, then re-plan in place. */
 int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                            double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs,
-                           int32_t *status, double *traj, int64_t traj_capacity_rows, double *yaw);
+                           int32_t *status, double *traj, int64_t traj_capacity_rows, double *yaw,
+                           double *first_yaw);
 /* MinimumSnap._calculate_yaws (minimum_snap.py:126-136) on its own, for B independent velocity
  * sequences of any length: sequence b = rows [offsets[b], offsets[b+1]) of velocities[.][3] (only
  * vx, vy are read); yaws[offsets[B]].  Headings of rows with |v_xy| >= 1e-3, np.unwrap over those,
@@ -200,10 +204,13 @@ int uavac_minsnap_sample(uavac_ctx *ctx, const double *coeffs, const double *tim
  * :232-251 + semi-implicit Euler free-body step; no contacts).
  *
  * State is struct-of-arrays over the batch (lane b = UAV b):
- *   state  [26][B] f64: rows 0-12  X = x y z | q0 q1 q2 q3 | vx vy vz | p q r   (quad.py:75-80)
+ *   state  [30][B] f64: rows 0-12  X = x y z | q0 q1 q2 q3 | vx vy vz | p q r   (quad.py:75-80)
  *                       rows 13-16 omega, rows 17-20 omega_command               (quad.py:83-86)
  *                       row  21    altitude integral error                       (controller.py:20)
  *                       row  22    thrust_cmd, rows 23-25 pqr_cmd                (main.py:26-27)
+ *                       rows 26-29 the yaw scan a plan-fed rollout carries when it is given no dense yaw column:
+ *                                  the row it stands before, heading seen (0/1), last heading, unwrap sum
+ *                                  (minimum_snap.py:126-136; zero after uavac_state_init, maintained by the kernel)
  *   istate [4][B]  i32: trajectory_index, inner_step (main.py:24-25), collided (sticky obstacle flag),
  *                       ground bookkeeping bits (UAVAC_GROUND_*; stays 0 in free flight)
  *   traj / row_offsets: as produced by uavac_minsnap_sample (UAV b follows mission b).
@@ -225,14 +232,18 @@ int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const doub
                               int n_obs);
 /* The same rollout fed by the plan instead of the sampled rows: the target row of every outer tick is
  * evaluated inside the kernel from the coefficients of the UAV's current segment (bit-identical to
- * the sampler's rows), the yaw comes from the dense yaw column uavac_minsnap_sample_yaw_dev writes.
- * coeffs [B][8m][3], seg_rows [B][m], row_offsets [B+1], yaw [row_offsets[B]], dt as given to the
- * sampler.  Same results as uavac_control_rollout_dev on the sampled trajectory, without its HBM
- * read traffic (80 B per UAV and outer tick, fetched as 128-byte lines). */
+ * the sampler's rows).  The yaw -- the one column that is a scan over all earlier rows -- comes
+ * either from the dense yaw column uavac_minsnap_sample_yaw_dev writes (yaw [row_offsets[B]]), or,
+ * with yaw == NULL, from the scan the vehicle carries itself in state rows 26-29 (it visits its rows
+ * in order), seeded with first_yaw [B] from the sampler; bit-identical either way, and in the second
+ * form no yaw byte is read or written.  coeffs [B][8m][3], seg_rows [B][m], row_offsets [B+1], dt
+ * as given to the sampler.  Same results as uavac_control_rollout_dev on the sampled trajectory,
+ * without its HBM read traffic (80 B per UAV and outer tick, fetched as 128-byte lines).  A cursor
+ * (istate row 0) that the caller moved is honoured: the carried scan is rebuilt from row 0 at launch. */
 int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *coeffs,
                                    const int32_t *seg_rows, const int64_t *row_offsets,
-                                   const double *yaw, int m, double dt, double *state,
-                                   int32_t *istate, int B, int K, double *state_log,
+                                   const double *yaw, const double *first_yaw, int m, double dt,
+                                   double *state, int32_t *istate, int B, int K, double *state_log,
                                    double *cmd_log, const double *aabbs, int n_obs);
 /* One tick (K = 1, no logs): the literal drop-in of tc.step() + simulation.step(). */
 int uavac_control_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
@@ -265,7 +276,7 @@ int uavac_dynamics_step(uavac_ctx *ctx, const uavac_vehicle *V, double *state, i
  * once per inner tick, with host code reading and writing quad.X / quad.omega in between.  The
  * trajectory rows of the B UAVs are uploaded once at creation; the state lives in pinned host memory
  * that is mapped into the device and that the tick kernels read and write IN PLACE:
- * uavac_pilot_state() -> [26][B] f64, uavac_pilot_istate() -> [4][B] i32 (layouts above), valid until
+ * uavac_pilot_state() -> [30][B] f64, uavac_pilot_istate() -> [4][B] i32 (layouts above), valid until
  * uavac_pilot_destroy.  uavac_pilot_tick runs the controller half (uavac_controller_tick), the
  * vehicle half (uavac_dynamics_step) or both on that state and returns when the results are
  * visible to the host: one kernel launch (or two) and one stream synchronisation per call, no

@@ -175,7 +175,7 @@ def test_reference_known_answers_through_probes(nat, ctx):
 def _single_uav_rollout(nat, ctx, traj, X0, K, omega0=None, aabbs=None):
     """B = 1 through the host-pointer twin of the rollout."""
     V = nat.Vehicle.default()
-    state = np.zeros((26, 1)); istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
+    state = np.zeros((nat.STATE_ROWS, 1)); istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
     ctx.call("uavac_state_init", C.byref(V), nat.np_ptr(nat.as_f64(X0[None, 0:3])), 1, 1, nat.np_ptr(state), nat.np_ptr(istate))
     state[0:13, 0] = X0
     if omega0 is not None:
@@ -271,7 +271,7 @@ def test_hover_and_free_fall_invariants(nat, ctx):
     slog, _, _, _ = _single_uav_rollout(nat, ctx, traj, X0, 100)
     assert np.allclose(slog[-1, 0:3], [1.0, 7.0, -1.0], atol=1e-6) and np.allclose(slog[-1, 7:10], 0, atol=1e-6)
     # free fall: empty trajectory (no outer update), rotors off, commands zero -> thrust floor only
-    state = np.zeros((26, 1)); state[3] = 1.0; state[2] = -10.0
+    state = np.zeros((nat.STATE_ROWS, 1)); state[3] = 1.0; state[2] = -10.0
     istate = np.zeros((nat.ISTATE_ROWS, 1), dtype=np.int32)
     offs = np.zeros(2, dtype=np.int64)
     slog = np.empty((10, 13, 1))
@@ -448,7 +448,7 @@ def test_outer_loop_every_F_ticks_and_cmd_log_only(eng, nat, F):
         _, c_ref = cc.rollout(traj, state, istate, K, Vc, log_state=False)
         assert col_err(clog[:, :, b].cpu().numpy(), c_ref) < TOL
         assert int(fleet.trajectory_index[b]) == istate[0] == min((K + F - 1) // F, len(traj) - 1)
-        assert col_err(fleet.state[:, b].cpu().numpy()[None], state[None]) < TOL
+        assert col_err(fleet.state[:26, b].cpu().numpy()[None], state[None]) < TOL
 
 
 def test_logged_rollout_beyond_one_launch_is_split_without_a_trace(eng):
@@ -464,7 +464,8 @@ def test_logged_rollout_beyond_one_launch_is_split_without_a_trace(eng):
     small = eng.fleet(eng.plan(wps[cut:], 3.0, 0.01))
     slog2, clog2 = small.rollout(K, state_log=True, cmd_log=True)
     assert torch.equal(slog[:, :, cut:], slog2) and torch.equal(clog[:, :, cut:], clog2)
-    assert torch.equal(big.state[:, cut:], small.state) and torch.equal(big.istate[:, cut:], small.istate)
+    # (rows 26-29 hold the yaw scan the plan-fed big fleet carries; the small one is row-fed and leaves them alone)
+    assert torch.equal(big.state[:26, cut:], small.state[:26]) and torch.equal(big.istate[:, cut:], small.istate)
     assert bool((slog[:, 3:7].norm(dim=1) - 1).abs().max() < 1e-12)          # every column of every tick was written
     nolog = eng.fleet(eng.plan(wps, 3.0, 0.01))
     nolog.rollout(K)                                                          # one launch, no log: same states
@@ -482,28 +483,54 @@ def test_logged_rollout_beyond_one_launch_is_split_without_a_trace(eng):
 
 
 def test_plan_fed_rollout_equals_row_fed_rollout(eng):
-    """Fleet(from_plan=True) evaluates every target row inside the kernel from the segment coefficients (+ the dense
-    yaw column); Fleet(from_plan=False) reads the sampled rows.  Same bits: states, logs, cursors -- in one launch,
-    across split launches (the cursor's segment / row-in-segment are rebuilt from the index) and tick by tick."""
+    """Fleet(from_plan=True) evaluates every target row inside the kernel from the segment coefficients and gets the yaw
+    either from the scan it carries itself (state rows 26-29, seeded with plan.first_yaw: the default) or from the dense
+    yaw column; Fleet(from_plan=False) reads the sampled rows.  Same bits all three ways: states, logs, cursors -- in one
+    launch, across split launches (the cursor's segment / row-in-segment are rebuilt from the index, the yaw scan is
+    carried in the state) and tick by tick."""
     import torch
     from oracle import minsnap_oracle as mo
     for B, m, K in ((130, 3, 2600), (257, 12, 700), (64, 1, 900)):
         wps = mo.synthetic_missions(B, m)
-        plan = eng.plan(wps, 3.0, 0.01)
+        wps[::5, 1:3, 0:2] = wps[::5, 0:1, 0:2]             # every fifth mission climbs first: no heading for hundreds of rows
+        plan = eng.plan(wps, 3.0, 0.01, dense_yaw=True)
         assert torch.equal(plan.yaw, plan.traj[:, 9])
-        a, b = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False)
-        assert a.from_plan and not b.from_plan
+        a, b, d = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False), eng.fleet(plan, from_plan=True, yaw_from="column")
+        assert a.from_plan and not b.from_plan and d.from_plan
         la, ca = a.rollout(K, state_log=True, cmd_log=True)
+        assert eng.ctx.last_rollout_kernel().endswith("true, false, true>")          # plan-fed, free flight, yaw scan
         lb, cb = b.rollout(K, state_log=True, cmd_log=True)
-        assert torch.equal(la, lb) and torch.equal(ca, cb)
-        assert torch.equal(a.state, b.state) and torch.equal(a.istate, b.istate)
+        ld, cd = d.rollout(K, state_log=True, cmd_log=True)
+        assert eng.ctx.last_rollout_kernel().endswith("true, false, false>")         # plan-fed, yaw from the dense column
+        assert torch.equal(la, lb) and torch.equal(ca, cb) and torch.equal(la, ld) and torch.equal(ca, cd)
+        assert torch.equal(a.state[:26], b.state[:26]) and torch.equal(a.istate, b.istate)
+        assert torch.equal(d.state[:26], b.state[:26]) and torch.equal(d.istate, b.istate)
         c = eng.fleet(plan, from_plan=True)
         for k in (1, 7, 16 * 10, 333, K - 1 - 7 - 160 - 333):           # odd split points, one past a yaw refill
             c.rollout(k)
         assert torch.equal(c.state, a.state) and torch.equal(c.istate, a.istate)
+        # a cursor the caller moved (and a scan state that no longer matches it) is honoured: the scan is rebuilt
+        e1, e2 = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False)
+        for f in (e1, e2):
+            f.rollout(37)
+            f.istate[0] += 41                                         # jump ahead; e1's carried scan is now stale
+            f.istate[0].clamp_(max=(plan.row_offsets[1:] - plan.row_offsets[:-1] - 1).int())
+        e1.rollout(400); e2.rollout(400)
+        assert torch.equal(e1.state[:26], e2.state[:26]) and torch.equal(e1.istate, e2.istate)
+        # a launch that reads the column advances the cursor without touching the carried scan: the next scanning
+        # launch notices and rebuilds
+        g = eng.fleet(plan, from_plan=True)
+        g.rollout(150)
+        g.yaw_from = "column"; g.rollout(90)
+        g.yaw_from = "scan"; g.rollout(K - 240)
+        assert torch.equal(g.state[:26], a.state[:26]) and torch.equal(g.istate, a.istate)
     # far beyond the end of the trajectory the last row is held
     a.rollout(3000); b.rollout(3000)
-    assert torch.equal(a.state, b.state) and torch.equal(a.istate, b.istate)
+    assert torch.equal(a.state[:26], b.state[:26]) and torch.equal(a.istate, b.istate)
+    # a reset starts the scan again
+    a.reset(); b.reset()
+    a.rollout(500); b.rollout(500)
+    assert torch.equal(a.state[:26], b.state[:26])
 
 
 def test_fleet_picks_the_rollout_feed_by_batch_size(eng):
@@ -538,7 +565,7 @@ def test_plan_fed_rollout_corner_shapes(eng, nat, m, velocity, dt, F):
     la, ca = a.rollout(K, state_log=True, cmd_log=True, aabbs=aabbs)
     lb, cb = b.rollout(K, state_log=True, cmd_log=True, aabbs=aabbs)
     assert torch.equal(la, lb) and torch.equal(ca, cb)
-    assert torch.equal(a.state, b.state) and torch.equal(a.istate, b.istate)
+    assert torch.equal(a.state[:26], b.state[:26]) and torch.equal(a.istate, b.istate)      # rows 26-29: a's carried yaw scan
     rows = (plan.row_offsets[1:] - plan.row_offsets[:-1]).cpu().numpy()
     assert rows.min() >= m and (a.trajectory_index.cpu().numpy() == np.minimum(K // F + (1 if K % F else 0), rows - 1)).all()
     only_cmd_a, only_cmd_b = eng.fleet(plan, vehicle=V, from_plan=True), eng.fleet(plan, vehicle=V, from_plan=False)
@@ -592,20 +619,24 @@ def test_two_contexts_in_two_threads_do_not_disturb_each_other(nat):
 def test_plan_fed_entry_points_reject_bad_arguments(eng, nat):
     import torch
     from oracle import minsnap_oracle as mo
-    plan = eng.plan(mo.synthetic_missions(8, 2), 3.0, 0.01)
+    plan = eng.plan(mo.synthetic_missions(8, 2), 3.0, 0.01, dense_yaw=True)
     fleet = eng.fleet(plan, from_plan=True)
     lib, h, V = nat.lib(), eng.ctx._h, C.byref(fleet.vehicle)
     P = lambda t: C.c_void_p(t.data_ptr())                  # noqa: E731
-    good = (P(plan.coeffs), P(plan.seg_rows), P(plan.row_offsets), P(plan.yaw), plan.m, plan.dt, P(fleet.state), P(fleet.istate), 8, 5,
-            None, None, None, 0)
+    good = (P(plan.coeffs), P(plan.seg_rows), P(plan.row_offsets), P(plan.yaw), P(plan.first_yaw), plan.m, plan.dt, P(fleet.state),
+            P(fleet.istate), 8, 5, None, None, None, 0)
 
     def call(*a):
         return lib.uavac_control_rollout_plan_dev(h, V, *a)
     assert call(*good) == nat.OK
-    for i, bad in ((0, None), (1, None), (3, None), (4, 0), (4, 65), (5, 0.0), (5, float("nan")), (6, None), (8, 0), (9, -1), (13, -2)):
+    for i, bad in ((0, None), (1, None), (5, 0), (5, 65), (6, 0.0), (6, float("nan")), (7, None), (9, 0), (10, -1), (14, -2)):
         args = list(good); args[i] = bad
         assert call(*args) == nat.EINVAL, i
-    assert call(*(good[:9] + (0,) + good[10:])) == nat.OK            # K = 0: nothing to do
+    only_scan = list(good); only_scan[3] = None
+    only_col = list(good); only_col[4] = None
+    neither = list(good); neither[3] = neither[4] = None
+    assert call(*only_scan) == nat.OK and call(*only_col) == nat.OK and call(*neither) == nat.EINVAL
+    assert call(*(good[:10] + (0,) + good[11:])) == nat.OK           # K = 0: nothing to do
     assert lib.uavac_minsnap_sample_yaw_dev(h, P(plan.coeffs), P(plan.times), P(plan.seg_rows), P(plan.row_offsets), 8, 2, 0.01,
                                             P(plan.traj), None) == nat.EINVAL
     torch.cuda.synchronize()

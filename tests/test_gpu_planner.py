@@ -409,7 +409,7 @@ def test_randomised_shapes_velocities_and_steps(eng):
 
 
 def test_dense_yaw_column_equals_the_rows_yaw(eng):
-    """Plan.yaw (written in groups of four chunks, with the back-fill of leading rows patched in LDS or in HBM
+    """Plan.yaw (written in groups of eight chunks, with the back-fill of leading rows patched in LDS or in HBM
     depending on whether the group had left) is column 9 of the rows, bit for bit -- including missions whose first
     usable heading comes after several chunks and missions shorter than one group."""
     import torch
@@ -418,7 +418,9 @@ def test_dense_yaw_column_equals_the_rows_yaw(eng):
     for B, m, vel, dt in ((200, 12, 3.0, 0.01), (64, 1, 3.0, 0.01), (77, 3, 0.4, 0.002), (50, 20, 6.0, 0.05)):
         wps = mo.synthetic_missions(B, m)
         wps[::3, 1:3, 0:2] = wps[::3, 0:1, 0:2]             # first legs vertical: no heading for hundreds of rows
-        plan = eng.plan(wps + rng.normal(0, 1e-9, wps.shape) * 0, vel, dt)
+        plan = eng.plan(wps + rng.normal(0, 1e-9, wps.shape) * 0, vel, dt, dense_yaw=True)
         assert torch.equal(plan.yaw, plan.traj[:, 9])
         eng.sample(plan)
         assert torch.equal(plan.yaw, plan.traj[:, 9])
+        # the missions' first headings: what the rows before the first usable heading hold, i.e. row 0's yaw
+        assert torch.equal(plan.first_yaw, plan.traj[plan.row_offsets[:-1], 9])

@@ -74,8 +74,8 @@ def test_replan_is_bit_identical_to_the_separate_calls_and_checks_capacity(eng, 
     from oracle import minsnap_oracle as mo
     wps = mo.synthetic_missions(300, 8)
     plan = eng.plan(wps, 3.0, 0.01)
-    ref = {k: getattr(plan, k).clone() for k in ("times", "seg_rows", "row_offsets", "coeffs", "traj", "yaw")}
-    for k in ("times", "coeffs", "traj", "yaw"):
+    ref = {k: getattr(plan, k).clone() for k in ("times", "seg_rows", "row_offsets", "coeffs", "traj", "first_yaw")}
+    for k in ("times", "coeffs", "traj", "first_yaw"):
         getattr(plan, k).fill_(float("nan"))
     plan.seg_rows.zero_(); plan.row_offsets.zero_()
     eng.replan(plan)
@@ -138,7 +138,7 @@ def test_yaw_scan_matches_reference_on_crafted_and_long_sequences(eng):
 
 def test_sampler_yaw_equals_standalone_scan_of_its_own_velocities(eng):
     from oracle import minsnap_oracle as mo
-    plan = eng.plan(mo.synthetic_missions(64, 12), 3.0, 0.01)
+    plan = eng.plan(mo.synthetic_missions(64, 12), 3.0, 0.01, dense_yaw=True)
     y = eng.yaw_scan(plan.traj[:, 3:6].contiguous(), plan.row_offsets)
     import torch
     assert torch.equal(y, plan.traj[:, 9].contiguous()) and torch.equal(y, plan.yaw)
@@ -203,7 +203,7 @@ def test_rollout_aligner_launch_does_not_change_a_bit(nat):
         plan = e.plan(wps, 3.0, 0.01)
         fleet = e.fleet(plan)
         slog, _ = fleet.rollout(K, state_log=True)
-        assert e.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, true, false>"
+        assert e.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, true, false, true>"
         logs.append((slog, fleet.state.clone(), fleet.istate.clone()))
         del fleet, plan
     assert torch.equal(logs[1][0], logs[0][0]) and torch.equal(logs[1][1], logs[0][1]) and torch.equal(logs[1][2], logs[0][2])
@@ -234,7 +234,7 @@ def test_ground_takeoff_matches_oracle_and_free_flight_is_untouched(eng, nat):
     eng._bind_stream()
     eng.ctx.call("uavac_state_init_dev", C.byref(V), P(pos), 1, 0, P(state), P(istate))
     eng.ctx.call("uavac_control_rollout_dev", C.byref(V), P(rows), P(offs), P(state), P(istate), 1, K, P(log), None, None, 0)
-    assert eng.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, false, true>"
+    assert eng.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, false, true, false>"
     Vc = cc.Vehicle.default()
     Vc.ground = 1
     s0, i0 = cc.initial_state(traj[0, 0:3], Vc, hover=False)
@@ -251,7 +251,7 @@ def test_ground_takeoff_matches_oracle_and_free_flight_is_untouched(eng, nat):
     a, b = eng.fleet(plan), eng.fleet(plan, vehicle=Vg)
     la, _ = a.rollout(700, state_log=True)
     lb, _ = b.rollout(700, state_log=True)
-    assert torch.equal(la, lb) and torch.equal(a.state, b.state) and torch.equal(a.istate[:3], b.istate[:3])
+    assert torch.equal(la, lb) and torch.equal(a.state[:26], b.state[:26]) and torch.equal(a.istate[:3], b.istate[:3])
     assert bool((b.istate[3] == nat.GROUND_TAKEN_OFF).all()) and bool((a.istate[3] == 0).all())
 
 
@@ -395,14 +395,12 @@ def test_plan_chain_edge_sizes_and_optional_outputs(eng, nat):
         plan = eng.plan(wps, 3.0, 0.01)
         ref = plan.traj.clone()
         plan.traj.zero_()
-        yaw, plan.yaw = plan.yaw, None
         eng._bind_stream()
         eng.ctx.call("uavac_minsnap_plan_dev", C.c_void_p(plan.waypoints.data_ptr()), plan.B, plan.m, plan.velocity, plan.dt,
                      C.c_void_p(plan.times.data_ptr()), C.c_void_p(plan.seg_rows.data_ptr()), C.c_void_p(plan.row_offsets.data_ptr()),
                      C.c_void_p(plan.coeffs.data_ptr()), C.c_void_p(plan.status.data_ptr()), C.c_void_p(plan.traj.data_ptr()),
-                     int(plan.traj.shape[0]), None)
+                     int(plan.traj.shape[0]), None, None)
         assert torch.equal(plan.traj, ref) and eng.take_flags() == [0, 0, 0, 0]
-        plan.yaw = yaw
         assert col_err(plan.mission(4), mo.plan(wps[4], 3.0, 0.01, method="solve")) < 1e-6
     plan = eng.plan(np.array([[[0.0, 0.0, -1.0], [3.0, 0.0, -1.0]]]), 1.0, 0.01)           # T = 3 * 1.5 = 4.5 s, along x
     jerk, snap = eng.sample_derivatives(plan)

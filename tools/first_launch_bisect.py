@@ -21,7 +21,7 @@ M, CH, NL = 12, 1000, 10
 dev = "cuda:0"
 eng = Engine(dev)
 wps = missions(B, M, 0, B)
-plan = eng.plan(wps, 3.0, 0.01)
+plan = eng.plan(wps, 3.0, 0.01, dense_yaw=True)
 fleet = eng.fleet(plan)
 log = torch.empty((CH, 13, B), dtype=torch.float64, device=dev)
 log2 = torch.empty((CH, 13, B), dtype=torch.float64, device=dev)
@@ -104,9 +104,10 @@ arms.append(run("G bench step, row-fed kernel", g_rows))
 
 # H: yaw removed from the picture: the vehicles start aligned with their first leg (target yaw == heading at start)
 # -> done by zeroing the dense yaw column and the yaw column of the rows after sampling (psi_des = 0 = initial psi)
+fleet_col = eng.fleet(plan, yaw_from="column")          # this arm needs the rollout that READS the yaw column
 def h_noyaw():
-    eng.solve(plan); eng.sample(plan); plan.yaw.zero_(); fleet.reset()
-    return launches()
+    eng.solve(plan); eng.sample(plan); plan.yaw.zero_(); fleet_col.reset()
+    return launches(fl=fleet_col)
 arms.append(run("H bench step with the target yaw forced to 0 (no initial yaw slew)", h_noyaw))
 eng.sample(plan)
 

@@ -22,7 +22,7 @@ def plan():
 traj = plan()
 t0 = time.perf_counter(); traj = plan(); t1 = time.perf_counter()
 V = nat.Vehicle.default()
-state = np.zeros((26, B)); istate = np.zeros((nat.ISTATE_ROWS, B), np.int32)
+state = np.zeros((nat.STATE_ROWS, B)); istate = np.zeros((nat.ISTATE_ROWS, B), np.int32)
 ctx.call("uavac_state_init", C.byref(V), nat.np_ptr(np.ascontiguousarray(wps[:, 0, :])), B, 1, nat.np_ptr(state), nat.np_ptr(istate))
 log = np.empty((K, 13, B))
 def roll():

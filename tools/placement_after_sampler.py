@@ -29,7 +29,7 @@ lib = C.CDLL(os.path.join(ROOT, "tools", "libwave_census.so"))
 lib.wave_census.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
 lib.noop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
 eng = Engine(dev)
-plan = eng.plan(missions(B, M, 0, B), 3.0, 0.01)
+plan = eng.plan(missions(B, M, 0, B), 3.0, 0.01, dense_yaw=True)
 fleet = eng.fleet(plan)
 log = torch.empty((CH, 13, B), dtype=torch.float64, device=dev)
 out = torch.zeros((2048, 2), dtype=torch.int32, device=dev)

@@ -72,7 +72,7 @@ def engine_arm(tag):
     global _eng, _plan
     if "_eng" not in globals():
         _eng = Engine("cuda:0")
-        _plan = _eng.plan(missions(B, M, 0, B), 3.0, 0.01)
+        _plan = _eng.plan(missions(B, M, 0, B), 3.0, 0.01, dense_yaw=True)
     y = _plan.yaw
     t_sy = timed(lambda: _eng.sample(_plan), reps=10)
     _plan.yaw = None

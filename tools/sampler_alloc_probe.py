@@ -9,7 +9,7 @@ from bench import missions
 from uav_ac.fleet import Engine
 B, M = 65536, 12
 eng = Engine("cuda:0")
-plan = eng.plan(missions(B, M, 0, B), 3.0, 0.01)
+plan = eng.plan(missions(B, M, 0, B), 3.0, 0.01, dense_yaw=True)
 N = plan.total_rows
 def passes(n, between=None):
     out = []

@@ -7,7 +7,7 @@ from bench import missions
 from uav_ac.fleet import Engine
 B = 65536
 eng = Engine("cuda:0")
-plan = eng.plan(missions(B, 12, 0, B), 3.0, 0.01)
+plan = eng.plan(missions(B, 12, 0, B), 3.0, 0.01, dense_yaw=True)
 yaw = plan.yaw
 for label, y in (("rows + yaw column", yaw), ("rows only", None), ("rows + yaw column", yaw), ("rows only", None)):
     plan.yaw = y

@@ -28,6 +28,7 @@
 
 #include "control_law.h"
 #include "minsnap_eval.h"
+#include "minsnap_yaw.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -104,7 +105,14 @@ __device__ __forceinline__ VehK outer_constants() {
 // drops from 1.3 GB to 0.1 GB at B = 65 536.  Coefficients [24][64] and yaws [16][64] of a compute wave live in LDS.
 constexpr int kPolyTileDoubles = (24 + 16) * 64;
 
-template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND>
+// YAWSCAN (with POLY): the yaw of a target row -- the one column that is a scan over all earlier rows -- is not read from a
+// dense column either: the vehicle visits its rows in order, one per outer tick, so it carries the scan itself (has a
+// heading been seen, the last one, the running sum of np.unwrap's corrections: state rows 27-29, with row 26 saying
+// which row they stand before) and evaluates minimum_snap.py:126-136 for the row at hand with the sampler's own
+// functions (minsnap_yaw.h; the sampler sums the corrections in the same left-to-right order).  Rows before a mission's
+// first heading take P.first_yaw[b].  A cursor that does not match the carried scan (a caller moved it, another kernel
+// advanced it) is caught at launch and the scan is rebuilt from row 0.  No yaw bytes are read or written at all.
+template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN>
 __global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD) ? 64 * SW : 0))
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
@@ -227,7 +235,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     double *yw = cf + 24 * 64;                                                                          // yw[j * 64]
     const int32_t *seg_rows = POLY ? P.seg_rows + (size_t)bb * P.m : nullptr;
     const double *mission_coeffs = POLY ? P.coeffs + (size_t)bb * 24 * P.m : nullptr;
-    const double *yaws = POLY ? P.yaw + off : nullptr;
+    const double *yaws = (POLY && !YAWSCAN) ? P.yaw + off : nullptr;
     int seg = 0, rin = 0, srows = 0, ybase = 0;
     auto load_coeffs = [&](int s_) {
         const double *src = mission_coeffs + 24 * s_;
@@ -238,14 +246,45 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 #pragma unroll
         for (int j = 0; j < 16; ++j) yw[j * 64] = yaws[min(base_ + j, nrows - 1)];
     };
+    // YAWSCAN: the carried scan (state rows 26-29)
+    int yhas = 0;
+    double yprev = 0.0, ysum = 0.0, first_yaw = 0.0;
     if (POLY && nrows > 0) {
         idx = min(max(idx, 0), nrows - 1);
+        if (YAWSCAN) {
+            first_yaw = P.first_yaw[bb];
+            const double scan_row = state[26 * sB + bb];
+            if (scan_row == (double)idx) {
+                yhas = state[27 * sB + bb] != 0.0;
+                yprev = state[28 * sB + bb];
+                ysum = state[29 * sB + bb];
+            } else {
+                // the cursor is not where the carried scan stands: rebuild it from the mission's first row (rare: a
+                // caller moved the cursor, or a launch without YAWSCAN advanced it)
+                int s_ = 0, r_ = 0, n_ = seg_rows[0];
+                load_coeffs(0);
+                for (int row = 0; row < idx; ++row) {
+                    while (r_ >= n_ && s_ + 1 < P.m) { r_ -= n_; ++s_; n_ = seg_rows[s_]; load_coeffs(s_); }
+                    double x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_;
+                    minsnap_eval_row<64>(cf, (double)r_ * P.dt, x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_);
+                    if (uavac_yaw::has_heading(vx_, vy_)) {
+                        const double a_ = atan2(vy_, vx_);
+                        if (yhas) ysum = ysum + uavac_yaw::unwrap_correction(a_ - yprev);
+                        yhas = 1;
+                        yprev = a_;
+                    }
+                    ++r_;
+                }
+            }
+        }
         rin = idx;
         srows = seg_rows[0];
         while (seg + 1 < P.m && rin >= srows) { rin -= srows; ++seg; srows = seg_rows[seg]; }
         load_coeffs(seg);
-        ybase = idx;
-        load_yaws(ybase);
+        if (!YAWSCAN) {
+            ybase = idx;
+            load_yaws(ybase);
+        }
     }
 
     // 1/|q|^2 of the caller-supplied attitude; the free-body step leaves q unit, so 1 from then on
@@ -260,7 +299,19 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             double tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az, tg_yaw;
             if (POLY) {
                 minsnap_eval_row<64>(cf, (double)rin * P.dt, tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az);
-                tg_yaw = yw[(idx - ybase) * 64];
+                if (YAWSCAN) {
+                    // this row's yaw from the carried scan (minimum_snap.py:126-136); committed below only if the cursor moves on
+                    const bool yvalid = uavac_yaw::has_heading(tg_vx, tg_vy);
+                    const double yang = yvalid ? atan2(tg_vy, tg_vx) : 0.0;
+                    const double ycum = (yvalid && yhas) ? ysum + uavac_yaw::unwrap_correction(yang - yprev) : ysum;
+                    tg_yaw = yvalid ? yang + ycum : (yhas ? yprev + ysum : first_yaw);
+                    if (idx + 1 < nrows) {
+                        if (yvalid) { yhas = 1; yprev = yang; }
+                        ysum = ycum;
+                    }
+                } else {
+                    tg_yaw = yw[(idx - ybase) * 64];
+                }
             } else {
                 row_wait(nxt);
                 tg_x = row_col(nxt, 0); tg_y = row_col(nxt, 1); tg_z = row_col(nxt, 2);
@@ -287,7 +338,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                         while (rin >= srows && seg + 1 < P.m) { rin -= srows; ++seg; srows = seg_rows[seg]; }
                         load_coeffs(seg);
                     }
-                    if (idx - ybase == 16) { ybase = idx; load_yaws(ybase); }
+                    if (!YAWSCAN && idx - ybase == 16) { ybase = idx; load_yaws(ybase); }
                 }
             } else {
                 idx = min(idx + 1, nrows - 1);
@@ -349,6 +400,12 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     istate[1 * sB + b] = inner;
     if (!(AABB && LOG_STATE && CW == SW)) istate[2 * sB + b] = collided;
     if (GROUND) istate[3 * sB + b] = gbits;
+    if (POLY && YAWSCAN) {
+        state[26 * sB + b] = (double)idx;
+        state[27 * sB + b] = yhas ? 1.0 : 0.0;
+        state[28 * sB + b] = yprev;
+        state[29 * sB + b] = ysum;
+    }
 }
 
 __global__ void state_init_kernel(const VehK V, const double *__restrict__ positions, int B, int hover,
@@ -382,7 +439,7 @@ __global__ void __launch_bounds__(128) rollout_align_kernel() {}
 // 8 waves the dispatcher always deals round the 4 SIMDs evenly, so that no aligner is needed -- was measured at 1.65 ms
 // per 1 000 ticks against 1.33 ms: the per-tick barrier then couples eight waves.  The kernel keeps its CW / SW
 // parameters; only <1, 1> is instantiated.)
-template <bool LS, bool LC, bool AB, bool POLY, bool GR>
+template <bool LS, bool LC, bool AB, bool POLY, bool GR, bool YS>
 void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                   int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                   const PlanRef &P) {
@@ -392,7 +449,7 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0);
     constexpr int threads = NU + (LOGGING ? 64 * SW : 0);
     const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * kPolyTileDoubles : 0));
-    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR>;
+    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // With logs, batches beyond one compute wave per SIMD go out as consecutive launches of kColumnsPerLaunch UAVs:
     // measured per 1 000 ticks, B = 131 072 in one launch 4.04 ms, as 2 x 65 536 3.3 ms (two workgroups per SIMD
@@ -408,8 +465,8 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     }
     auto tf = [](bool v) { return v ? "true" : "false"; };
     char name[176];
-    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
-             tf(GR));
+    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
+             tf(GR), tf(YS));
     ctx->last_rollout = name;
 }
 
@@ -418,12 +475,15 @@ void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int
                     int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                     const PlanRef *plan) {
 #define UAVAC_SHAPE_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs
-    if (plan) {
-        if (V.ground) launch_shape<LS, LC, AB, true, true>(UAVAC_SHAPE_ARGS, *plan);
-        else launch_shape<LS, LC, AB, true, false>(UAVAC_SHAPE_ARGS, *plan);
+    if (plan && !plan->yaw) {                       // the rollout scans the yaw itself
+        if (V.ground) launch_shape<LS, LC, AB, true, true, true>(UAVAC_SHAPE_ARGS, *plan);
+        else launch_shape<LS, LC, AB, true, false, true>(UAVAC_SHAPE_ARGS, *plan);
+    } else if (plan) {
+        if (V.ground) launch_shape<LS, LC, AB, true, true, false>(UAVAC_SHAPE_ARGS, *plan);
+        else launch_shape<LS, LC, AB, true, false, false>(UAVAC_SHAPE_ARGS, *plan);
     } else {
-        if (V.ground) launch_shape<LS, LC, AB, false, true>(UAVAC_SHAPE_ARGS, PlanRef{});
-        else launch_shape<LS, LC, AB, false, false>(UAVAC_SHAPE_ARGS, PlanRef{});
+        if (V.ground) launch_shape<LS, LC, AB, false, true, false>(UAVAC_SHAPE_ARGS, PlanRef{});
+        else launch_shape<LS, LC, AB, false, false, false>(UAVAC_SHAPE_ARGS, PlanRef{});
     }
 #undef UAVAC_SHAPE_ARGS
 }

@@ -14,30 +14,12 @@
 
 #include "uavac_internal.h"
 #include "minsnap_eval.h"
+#include "minsnap_yaw.h"
 
 namespace {
 
 constexpr int SB = 64;                  // rows per chunk == threads per workgroup == one wavefront
-constexpr double kPi = 3.141592653589793238462643383279502884;
-constexpr double kTwoPi = 2.0 * kPi;
-
-// floored modulo of NumPy's float `%` for a positive divisor
-__device__ __forceinline__ double floored_mod(double a, double b) {
-    double r = fmod(a, b);
-    if (r != 0.0) { if (r < 0.0) r += b; } else { r = 0.0; }
-    return r;
-}
-
-// np.unwrap's per-step correction for dd = p[i] - p[i-1]:
-//     ddmod = mod(dd + pi, 2 pi) - pi ; ddmod[(ddmod == -pi) & (dd > 0)] = pi ; corr = ddmod - dd ; corr[|dd| < pi] = 0
-// Headings of consecutive samples rarely jump by pi or more, and NumPy discards the modulo's result whenever they do
-// not: the (long) fp64 fmod runs only for the lanes that need it, i.e. for almost no wave.
-__device__ __forceinline__ double unwrap_correction(double dd) {
-    if (fabs(dd) < kPi) return 0.0;
-    double ddmod = floored_mod(dd + kPi, kTwoPi) - kPi;
-    if (ddmod == -kPi && dd > 0.0) ddmod = kPi;
-    return ddmod - dd;
-}
+using namespace uavac_yaw;
 
 // double held by lane `l` (wave-uniform index): two v_readlane instead of two LDS-pipe bpermutes
 __device__ __forceinline__ double lane_value(double v, int l) {
@@ -48,16 +30,6 @@ __device__ __forceinline__ double lane_value(double v, int l) {
 __device__ __forceinline__ int segment_of(const int *__restrict__ pre, int m, int r, int s) {
     while (s + 1 < m && r >= pre[s + 1]) ++s;
     return s;
-}
-
-// |v_xy| >= MIN_HORIZONTAL_SPEED_FOR_YAW as NumPy evaluates it (np.linalg.norm(..., axis=1) = sqrt(add.reduce(x * x)):
-// two rounded products, one rounded sum -- no fused multiply-add), without the square root: sqrt is correctly rounded and
-// monotonic, so sqrt(s) >= 1e-3 holds exactly for s >= s*, s* the smallest double whose root rounds to >= 1e-3.  That is
-// 0x1.0c6f7a0b5ed8dp-20 (= the double nearest 1e-6; its predecessor's root is below 1e-3 -- checked with exact
-// rationals against ((1e-3 + pred(1e-3)) / 2)^2).  Infinities pass and NaNs fail either way.
-constexpr double kMinSpeedSquared = 0x1.0c6f7a0b5ed8dp-20;
-__device__ __forceinline__ bool has_heading(double vx, double vy) {
-    return __dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy)) >= kMinSpeedSquared;
 }
 
 // State of _calculate_yaws carried from one 64-row chunk to the next (wave-uniform): has a usable heading been seen,
@@ -80,15 +52,22 @@ __device__ __forceinline__ double yaw_chunk(bool valid, double ang, int lane, Ya
     double prev_ang = __shfl(ang, prev_has ? 63 - __clzll((long long)lower) : 0);
     if (!prev_has && carry.has) { prev_has = true; prev_ang = carry.ang; }
     const double corr = (valid && prev_has) ? unwrap_correction(ang - prev_ang) : 0.0;
-    double incl = corr;                       // inclusive prefix sum of the corrections in this chunk
-    if (__ballot(corr != 0.0) != 0ull) {      // headings rarely wrap: most chunks skip the scan
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
+    // np.cumsum of the corrections, in NumPy's own order: left to right.  Headings rarely wrap, so the running sum is
+    // advanced lane by lane over the few lanes that hold a non-zero correction (adding the zeros of the others would not
+    // change a bit); every row then takes the sum up to and including itself.  The rollout, which visits the rows one by
+    // one, reproduces exactly this sequence when it scans the yaw itself (control_rollout.hip, YAWSCAN).
+    double cum = carry.sum;
+    unsigned long long wraps = __ballot(corr != 0.0);
+    if (wraps != 0ull) {
+        double run = carry.sum;
+        while (wraps != 0ull) {
+            const int j = __builtin_ctzll(wraps);
+            wraps &= wraps - 1ull;
+            run = run + lane_value(corr, j);
+            if (lane >= j) cum = run;
         }
+        carry.sum = run;
     }
-    const double cum = carry.sum + incl;
     // rows before the mission's first valid heading take that heading (np.searchsorted(...)-1 clipped to 0)
     first_here = !carry.has && mask != 0ull;
     const int first_lane = first_here ? __builtin_ctzll(mask) : 0;
@@ -96,7 +75,6 @@ __device__ __forceinline__ double yaw_chunk(bool valid, double ang, int lane, Ya
     double yaw;
     if (valid || prev_has) yaw = (valid ? ang : prev_ang) + cum;
     else yaw = first_here ? first_yaw : 0.0;                   // 0 = placeholder, patched by the caller if needed
-    carry.sum += lane_value(incl, 63);
     if (mask != 0ull) { carry.has = true; carry.ang = lane_value(ang, 63 - __clzll((long long)mask)); }
     return yaw;
 }
@@ -114,7 +92,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                                                            const double *__restrict__ aabb, int32_t *__restrict__ hit,
                                                            double *__restrict__ yaw_dense, double *__restrict__ jerk,
                                                            double *__restrict__ snap, int64_t capacity_rows,
-                                                           int32_t *__restrict__ flags) {
+                                                           int32_t *__restrict__ flags, double *__restrict__ first_yaw_out) {
     extern __shared__ double lds[];
     double *stage = lds;                         // [SB*11]
     double *cl = stage + SB * UAVAC_TRAJ_COLS;   // [24*m] coefficients of this mission
@@ -149,6 +127,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     // carried across chunks (wave-uniform): has a valid heading been seen, its raw angle, the running
     // unwrap sum (np.cumsum of np.unwrap's corrections), and the heading used for the back-fill
     YawCarry carry;
+    double mission_first_yaw = 0.0;          // heading of the first row that has one (what rows before it take); 0 if none
     int s = 0;
     for (int c0 = 0; c0 < N; c0 += SB) {
         const int r = c0 + lane;
@@ -178,6 +157,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
         bool first_here;
         double first_yaw;
         const double yaw = yaw_chunk(valid, ang, lane, carry, first_here, first_yaw);
+        if (first_here) mission_first_yaw = first_yaw;
         if (first_here && c0 > 0) {
             // the first usable heading arrived after whole chunks of placeholders: patch their yaw column
             // (same wave, same addresses, program order => the later store wins)
@@ -233,6 +213,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
         if (((nel - head) & 1) && lane == 63) dst[nel - 1] = stage[nel - 1];
         lds_wave_fence();                         // the staged chunk is in registers / on its way; its stores stay in flight
     }
+    if (first_yaw_out && lane == 0) first_yaw_out[b] = mission_first_yaw;
 }
 
 // _calculate_yaws (minimum_snap.py:126-136) on its own: B independent velocity sequences, sequence b = rows
@@ -280,7 +261,7 @@ int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg
     if (hits) UAVAC_HIP(ctx, hipMemsetAsync(x.hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
 #define UAVAC_SAMPLE(H, D, Y)                                                                                          \
     hipLaunchKernelGGL((minsnap_sample_kernel<H, D, Y>), dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows, row_offsets, \
-                       B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags)
+                       B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags, x.first_yaw)
     if (hits) { if (derivs) UAVAC_SAMPLE(true, true, 8); else UAVAC_SAMPLE(true, false, 8); }
     else if (derivs) UAVAC_SAMPLE(false, true, 8);
     else if (yg == 1) UAVAC_SAMPLE(false, false, 1);

@@ -385,11 +385,12 @@ int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const do
 
 int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows,
                                     const int64_t *row_offsets, int B, int m, double dt, double *traj, double *yaw,
-                                    double *jerk, double *snap) {
+                                    double *first_yaw, double *jerk, double *snap) {
     UAVAC_ENTER(ctx);
     if (int rc = check_sample_args(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj)) return rc;
     SampleExtras x;
     x.yaw_dense = yaw;
+    x.first_yaw = first_yaw;
     x.jerk = jerk;
     x.snap = snap;
     return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
@@ -397,7 +398,7 @@ int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const 
 
 int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt, double *times,
                            int32_t *seg_rows, int64_t *row_offsets, double *coeffs, int32_t *status, double *traj,
-                           int64_t traj_capacity_rows, double *yaw) {
+                           int64_t traj_capacity_rows, double *yaw, double *first_yaw) {
     UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
     if (!times || !seg_rows || !row_offsets || !coeffs || !traj) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
@@ -409,6 +410,7 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
     if (int rc = uavac_launch_solve_bt(ctx, wp, times, B, m, coeffs, status)) return rc;
     SampleExtras x;
     x.yaw_dense = yaw;
+    x.first_yaw = first_yaw;
     x.capacity_rows = traj_capacity_rows;         // the sampler refuses (flag 2) instead of overrunning the buffer
     return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
 }
@@ -553,18 +555,19 @@ int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const doub
 }
 
 int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *coeffs, const int32_t *seg_rows,
-                                   const int64_t *row_offsets, const double *yaw, int m, double dt, double *state,
-                                   int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,
-                                   int n_obs) {
+                                   const int64_t *row_offsets, const double *yaw, const double *first_yaw, int m, double dt,
+                                   double *state, int32_t *istate, int B, int K, double *state_log, double *cmd_log,
+                                   const double *aabbs, int n_obs) {
     UAVAC_ENTER(ctx);
     if (int rc = uavac_check_vehicle(ctx, V)) return rc;
     if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
-    if (K < 0 || !seg_rows || !row_offsets || !yaw || !state || !istate || n_obs < 0)
+    if (K < 0 || !seg_rows || !row_offsets || !state || !istate || n_obs < 0)
         return uavac_fail(ctx, UAVAC_EINVAL, "bad size or null pointer");
+    if (!yaw && !first_yaw) return uavac_fail(ctx, UAVAC_EINVAL, "need the dense yaw column or the missions' first headings");
     if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
     if (K == 0) return UAVAC_OK;
     PlanRef plan;
-    plan.coeffs = coeffs; plan.seg_rows = seg_rows; plan.yaw = yaw; plan.dt = dt; plan.m = m;
+    plan.coeffs = coeffs; plan.seg_rows = seg_rows; plan.yaw = yaw; plan.first_yaw = first_yaw; plan.dt = dt; plan.m = m;
     return uavac_launch_rollout(ctx, uavac_make_vehk(*V), nullptr, row_offsets, state, istate, B, K, state_log, cmd_log,
                                 aabbs, n_obs, &plan);
 }

@@ -136,6 +136,7 @@ struct SampleExtras {
     const double *aabb = nullptr;    // [6] cuboid of the collision scan, with
     int32_t *hit = nullptr;          // [B][m] hit flags
     double *yaw_dense = nullptr;     // [rows] the yaw column on its own
+    double *first_yaw = nullptr;     // [B] heading of each mission's first row that has one (0 when none has)
     double *jerk = nullptr;          // [rows][3]
     double *snap = nullptr;          // [rows][3]
     int64_t capacity_rows = -1;      // rows the trajectory buffer holds; < 0: not checked
@@ -149,7 +150,8 @@ int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positio
 struct PlanRef {
     const double *coeffs = nullptr;      // [B][8m][3]
     const int32_t *seg_rows = nullptr;   // [B][m]
-    const double *yaw = nullptr;         // [row_offsets[B]] dense yaw column of the sampler
+    const double *yaw = nullptr;         // [row_offsets[B]] dense yaw column of the sampler, or NULL: the rollout scans the yaw
+    const double *first_yaw = nullptr;   // [B] (with yaw == NULL) heading the rows before a mission's first heading take
     double dt = 0.0;
     int m = 0;
 };

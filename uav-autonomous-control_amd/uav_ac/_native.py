@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libuavac.so")
 OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
 MAX_SEGMENTS = 64
-TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 26, 4, 12
+TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 30, 4, 12
 VERSION = 200
 GROUND_IN_CONTACT, GROUND_TAKEN_OFF, GROUND_HIT_AFTER_TAKEOFF = 1, 2, 4       # istate row 3 (include/uavac.h)
 
@@ -72,9 +72,9 @@ _SIGNATURES = {
     "uavac_minsnap_sample_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P]),
     "uavac_minsnap_sample_yaw_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_minsnap_sample_hits_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
-    "uavac_minsnap_sample_derivs_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
+    "uavac_minsnap_sample_derivs_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]),
     "uavac_minsnap_plan_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P, _P,
-                                          C.c_int64, _P]),
+                                          C.c_int64, _P, _P]),
     "uavac_yaw_scan_dev": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "uavac_yaw_scan": (C.c_int, [_P, _P, C.c_int64, _P]),
     "uavac_minsnap_row_counts": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
@@ -82,7 +82,7 @@ _SIGNATURES = {
     "uavac_minsnap_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "uavac_state_init_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
     "uavac_control_rollout_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
-    "uavac_control_rollout_plan_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_double, _P, _P,
+    "uavac_control_rollout_plan_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, _P, C.c_int, C.c_double, _P, _P,
                                                   C.c_int, C.c_int, _P, _P, _P, C.c_int]),
     "uavac_control_step_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
     "uavac_state_init": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
@@ -231,7 +231,7 @@ PILOT_CONTROLLER, PILOT_DYNAMICS = 1, 2
 
 class Pilot:
     """Resident tick-by-tick session (`uavac_pilot_*`): trajectory rows on the device, state in pinned mapped host memory
-    exposed as NumPy views `state` (26, B) and `istate` (4, B) that the kernels update in place."""
+    exposed as NumPy views `state` (30, B) and `istate` (4, B) that the kernels update in place."""
 
     def __init__(self, ctx: Context, traj: np.ndarray, row_offsets: np.ndarray):
         self._ctx = ctx

@@ -43,7 +43,8 @@ class Plan:
     status: "object"         # (B,) i32: 0 ok, 1 singular
     traj: "object"           # (N, 11) f64, missions back to back
     total_rows: int
-    yaw: "object" = None     # (N,) f64: the yaw column on its own (== traj[:, 9]); feeds the plan-fed rollout
+    yaw: "object" = None     # (N,) f64 or None: the yaw column on its own (== traj[:, 9]); one way to feed the plan-fed rollout
+    first_yaw: "object" = None   # (B,) f64: heading of each mission's first row that has one; lets the rollout scan the yaw itself
 
     def mission(self, b: int) -> np.ndarray:
         """Rows of mission b as a fresh host array (N_b, 11) -- the reference's `full_trajectory`."""
@@ -127,10 +128,12 @@ class Engine:
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
 
     # -- planning ---------------------------------------------------------------
-    def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True) -> Plan:
+    def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True, dense_yaw: bool = False) -> Plan:
         """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124).
         `strict`: raise UavacError(ESINGULAR) when a mission's knot system is singular (a repeated waypoint) instead of
-        returning NaN coefficients for it; with strict=False inspect `plan.status`."""
+        returning NaN coefficients for it; with strict=False inspect `plan.status`.
+        `dense_yaw`: also keep the yaw column on its own (`plan.yaw`, 8 B per row).  Not needed to fly the plan: the
+        plan-fed rollout scans the yaw itself from `plan.first_yaw` (8 B per mission)."""
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -150,22 +153,23 @@ class Engine:
         self.ctx.call("uavac_minsnap_solve_dev", _ptr(wp), _ptr(times), B, m, _ptr(coeffs), _ptr(status))
         total = int(row_offsets[-1].item())                 # the one host sync: sizes the trajectory buffer
         traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
-        yaw = torch.empty((total,), dtype=torch.float64, **kw)
-        plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw)
+        yaw = torch.empty((total,), dtype=torch.float64, **kw) if dense_yaw else None
+        first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
+        plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw, first_yaw)
         self.sample(plan)
         if strict:
             self.check(plan)
         return plan
 
     def replan(self, plan: Plan):
-        """The whole chain again into plan's buffers -- times + row counts, offsets, solve, sampler + yaw column --
+        """The whole chain again into plan's buffers -- times + row counts, offsets, solve, sampler (+ yaw column) --
         enqueued by ONE call into the C ABI (`uavac_minsnap_plan_dev`): no allocation, no sync, no Python between
         the four launches.  The buffers keep their size: a plan that would need more rows than `plan.traj` holds is
         refused on the device (flag 2, see `take_flags`)."""
         self._bind_stream()
         self.ctx.call("uavac_minsnap_plan_dev", _ptr(plan.waypoints), plan.B, plan.m, plan.velocity, plan.dt,
                       _ptr(plan.times), _ptr(plan.seg_rows), _ptr(plan.row_offsets), _ptr(plan.coeffs), _ptr(plan.status),
-                      _ptr(plan.traj), int(plan.traj.shape[0]), _ptr(plan.yaw))
+                      _ptr(plan.traj), int(plan.traj.shape[0]), _ptr(plan.yaw), _ptr(plan.first_yaw))
 
     def take_flags(self):
         """Synchronise and return-and-clear the sticky device-side flags of the `_dev` planning entry points:
@@ -184,7 +188,7 @@ class Engine:
         snap = torch.empty((plan.total_rows, 3), dtype=torch.float64, device=self.device)
         self._bind_stream()
         self.ctx.call("uavac_minsnap_sample_derivs_dev", _ptr(plan.coeffs), _ptr(plan.seg_rows), _ptr(plan.row_offsets),
-                      plan.B, plan.m, plan.dt, _ptr(plan.traj), _ptr(plan.yaw), _ptr(jerk), _ptr(snap))
+                      plan.B, plan.m, plan.dt, _ptr(plan.traj), _ptr(plan.yaw), _ptr(plan.first_yaw), _ptr(jerk), _ptr(snap))
         return jerk, snap
 
     def yaw_scan(self, velocities, offsets=None):
@@ -341,14 +345,16 @@ class Engine:
                       _ptr(plan.coeffs), _ptr(plan.status))
 
     def sample(self, plan: Plan):
-        """Re-run the sampler + yaw scan into plan.traj (no allocation, no sync)."""
+        """Re-run the sampler + yaw scan into plan.traj (and plan.yaw / plan.first_yaw when the plan has them); no
+        allocation, no sync."""
         self._bind_stream()
-        if plan.yaw is None:
+        if plan.yaw is None and getattr(plan, "first_yaw", None) is None:
             self.ctx.call("uavac_minsnap_sample_dev", _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows),
                           _ptr(plan.row_offsets), plan.B, plan.m, plan.dt, _ptr(plan.traj))
         else:
-            self.ctx.call("uavac_minsnap_sample_yaw_dev", _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows),
-                          _ptr(plan.row_offsets), plan.B, plan.m, plan.dt, _ptr(plan.traj), _ptr(plan.yaw))
+            self.ctx.call("uavac_minsnap_sample_derivs_dev", _ptr(plan.coeffs), _ptr(plan.seg_rows), _ptr(plan.row_offsets),
+                          plan.B, plan.m, plan.dt, _ptr(plan.traj), _ptr(plan.yaw), _ptr(getattr(plan, "first_yaw", None)),
+                          None, None)
 
     def check(self, plan: Plan):
         """Raise like the C ABI's host twins would: singular knot systems (repeated waypoints)."""
@@ -435,27 +441,32 @@ class Engine:
 
     # -- control ----------------------------------------------------------------
     def fleet(self, plan: Plan, vehicle: Optional[nat.Vehicle] = None, hover: bool = True,
-              positions=None, from_plan=None) -> "Fleet":
-        return Fleet(self, plan, vehicle, hover, positions, from_plan)
+              positions=None, from_plan=None, yaw_from: str = "scan") -> "Fleet":
+        return Fleet(self, plan, vehicle, hover, positions, from_plan, yaw_from)
 
 
 class Fleet:
     """B UAVs tracking the B missions of a Plan: batched TrajectoryController + free-flight simulation."""
     PLAN_FED_MIN_BATCH = 40960
 
-    def __init__(self, engine: Engine, plan: Plan, vehicle=None, hover=True, positions=None, from_plan=None):
+    def __init__(self, engine: Engine, plan: Plan, vehicle=None, hover=True, positions=None, from_plan=None,
+                 yaw_from: str = "scan"):
         torch = engine._torch
         self.engine, self.plan = engine, plan
-        # from_plan: feed the rollout with the plan's coefficients + dense yaw column (rows evaluated in the kernel)
+        if yaw_from not in ("scan", "column"):
+            raise ValueError("yaw_from is 'scan' (the rollout carries the yaw scan) or 'column' (dense plan.yaw)")
+        self.yaw_from = yaw_from
+        # from_plan: feed the rollout with the plan's coefficients (rows evaluated in the kernel; the yaw scanned by the
+        # kernel from plan.first_yaw, or read from the dense column plan.yaw when only that exists)
         # instead of the sampled rows.  Same bits either way.  Default: when the plan carries them (a RaggedPlan does
         # not) and the batch is large enough for HBM traffic to be what limits the kernel -- measured per 1 000 logged
         # ticks on an MI355X, plan-fed / row-fed: B = 32 768 1.05 / 0.95 ms, 49 152 1.08 / 1.11, 65 536 1.28 / 1.44,
         # 131 072 2.58 / 3.01 (tools/plan_vs_rows.py); below ~40 000 UAVs the chip is not full and the extra
         # arithmetic of evaluating rows costs more than the reads it saves.
-        can = getattr(plan, "yaw", None) is not None and hasattr(plan, "coeffs")
+        can = hasattr(plan, "coeffs") and (getattr(plan, "first_yaw", None) is not None or getattr(plan, "yaw", None) is not None)
         self.from_plan = (can and plan.B >= self.PLAN_FED_MIN_BATCH) if from_plan is None else bool(from_plan)
         if self.from_plan and not can:
-            raise ValueError("this plan has no coefficients / yaw column to fly from")
+            raise ValueError("this plan has no coefficients / first headings / yaw column to fly from")
         self.vehicle = vehicle if vehicle is not None else nat.Vehicle.default()
         self.B = plan.B
         self.state = torch.empty((nat.STATE_ROWS, self.B), dtype=torch.float64, device=engine.device)
@@ -496,9 +507,16 @@ class Fleet:
         e._bind_stream()
         p = self.plan
         if self.from_plan:
-            # target rows are evaluated inside the kernel from the plan's coefficients (+ its dense yaw column)
+            # target rows are evaluated inside the kernel from the plan's coefficients; the yaw is scanned by the kernel
+            # (plan.first_yaw) unless only the dense column exists or `yaw_from="column"` was asked for
+            first = getattr(p, "first_yaw", None)
+            yaw_col = p.yaw if (self.yaw_from == "column" or first is None) else None
+            if yaw_col is None and first is None:
+                raise ValueError("this plan has neither first headings nor a dense yaw column")
+            if self.yaw_from == "column" and yaw_col is None:
+                raise ValueError("yaw_from='column' needs a plan made with dense_yaw=True")
             e.ctx.call("uavac_control_rollout_plan_dev", C.byref(self.vehicle), _ptr(p.coeffs), _ptr(p.seg_rows),
-                       _ptr(p.row_offsets), _ptr(p.yaw), p.m, float(p.dt), _ptr(self.state), _ptr(self.istate), self.B,
+                       _ptr(p.row_offsets), _ptr(yaw_col), _ptr(first), p.m, float(p.dt), _ptr(self.state), _ptr(self.istate), self.B,
                        int(K), _ptr(state_log), _ptr(cmd_log), _ptr(ab), n_obs)
         else:
             e.ctx.call("uavac_control_rollout_dev", C.byref(self.vehicle), _ptr(p.traj), _ptr(p.row_offsets),
