@@ -103,7 +103,7 @@ __device__ __forceinline__ VehK outer_constants() {
 // a time.  Per UAV and outer tick that is 8 B of yaw plus 192 B of coefficients per ~110 rows instead of an 80-B
 // row whose 128-B lines the log stream has evicted from L2 by the next outer tick: HBM read traffic per launch
 // drops from 1.3 GB to 0.1 GB at B = 65 536.  Coefficients [24][64] and yaws [16][64] of a compute wave live in LDS.
-constexpr int kPolyTileDoubles = (24 + 16) * 64;
+constexpr int poly_tile_doubles(bool yawscan) { return (24 + (yawscan ? 0 : 16)) * 64; }    // no yaw slots when the kernel scans the yaw
 
 // YAWSCAN (with POLY): the yaw of a target row -- the one column that is a scan over all earlier rows -- is not read from a
 // dense column either: the vehicle visits its rows in order, one per outer tick, so it carries the scan itself (has a
@@ -231,7 +231,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     if (!POLY && nrows > 0) row_issue(nxt, rows + (size_t)min(max(idx, 0), nrows - 1) * UAVAC_TRAJ_COLS);
 
     // POLY: segment / row-in-segment of the cursor, the segment's coefficients and the next 16 yaws, in LDS
-    double *cf = slab + (size_t)2 * NR * NU + (size_t)(tid >> 6) * kPolyTileDoubles + (tid & 63);      // cf[j * 64]
+    double *cf = slab + (size_t)2 * NR * NU + (size_t)(tid >> 6) * poly_tile_doubles(YAWSCAN) + (tid & 63);      // cf[j * 64]
     double *yw = cf + 24 * 64;                                                                          // yw[j * 64]
     const int32_t *seg_rows = POLY ? P.seg_rows + (size_t)bb * P.m : nullptr;
     const double *mission_coeffs = POLY ? P.coeffs + (size_t)bb * 24 * P.m : nullptr;
@@ -435,7 +435,10 @@ constexpr int kColumnsPerLaunch = 256 * 4 * 64;          // one 64-UAV compute w
 // launches).  After ANY kernel of 2-wave workgroups the placement is one compute + one store wave on every SIMD.
 __global__ void __launch_bounds__(128) rollout_align_kernel() {}
 
-// One compute + one store wave per 64 UAVs.  (Four compute + four store waves per 256 UAVs -- one workgroup per CU, whose
+// One compute + one store wave per 64 UAVs, one hand-over per tick.  (Two ticks per hand-over -- the compute wave fills two
+// slabs before the barrier, the store wave drains two after it; 2 x 2 slabs + the coefficient tile still fit four workgroups
+// per CU once the yaw tile is gone -- is bit-identical and changes nothing: 14.46-14.49 ms per bench step against
+// 14.49-14.54 (a throw-away probe on the round-2 tree).  The rendezvous is not what couples the stages.)  (Four compute + four store waves per 256 UAVs -- one workgroup per CU, whose
 // 8 waves the dispatcher always deals round the 4 SIMDs evenly, so that no aligner is needed -- was measured at 1.65 ms
 // per 1 000 ticks against 1.33 ms: the per-tick barrier then couples eight waves.  The kernel keeps its CW / SW
 // parameters; only <1, 1> is instantiated.)
@@ -448,7 +451,7 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     constexpr int NU = 64 * CW;
     constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0);
     constexpr int threads = NU + (LOGGING ? 64 * SW : 0);
-    const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * kPolyTileDoubles : 0));
+    const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0));
     auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // With logs, batches beyond one compute wave per SIMD go out as consecutive launches of kColumnsPerLaunch UAVs:
