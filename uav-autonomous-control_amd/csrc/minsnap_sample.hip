@@ -19,6 +19,8 @@
 namespace {
 
 constexpr int SB = 64;                  // rows per chunk == threads per workgroup == one wavefront
+constexpr int kCarryMax = 16;           // doubles of a chunk that may wait for the next one (less than one 128-byte line)
+constexpr int kStageDoubles = kCarryMax + SB * UAVAC_TRAJ_COLS;
 using namespace uavac_yaw;
 
 // double held by lane `l` (wave-uniform index): two v_readlane instead of two LDS-pipe bpermutes
@@ -94,8 +96,8 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                                                            double *__restrict__ snap, int64_t capacity_rows,
                                                            int32_t *__restrict__ flags, double *__restrict__ first_yaw_out) {
     extern __shared__ double lds[];
-    double *stage = lds;                         // [SB*11]
-    double *cl = stage + SB * UAVAC_TRAJ_COLS;   // [24*m] coefficients of this mission
+    double *stage = lds;                         // [kCarryMax + SB*11]: what is left of the previous chunk, then this chunk
+    double *cl = stage + kStageDoubles;          // [24*m] coefficients of this mission
     int *pre = reinterpret_cast<int *>(cl + 24 * m);   // [m+1] exclusive prefix of seg_rows
     // yaw column on its own: collected over kYawGroup chunks and written as one contiguous piece, so that the row
     // stream is interrupted a quarter as often (the dense column is 9 % of the bytes; written per chunk it cost up to 21 %)
@@ -128,6 +130,12 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     // unwrap sum (np.cumsum of np.unwrap's corrections), and the heading used for the back-fill
     YawCarry carry;
     double mission_first_yaw = 0.0;          // heading of the first row that has one (what rows before it take); 0 if none
+    // The rows leave in pieces that END on a 128-byte line of the output (a mission's rows start at a multiple of 88 bytes,
+    // so a 64-row chunk -- 44 lines' worth -- straddles lines at both ends): the doubles behind the last line boundary wait
+    // in LDS (`held` of them, at the front of `stage`) and go out with the next chunk.  Every line inside a mission is then
+    // written once, whole, by one run of stores; only a mission's first and last line are shared with its neighbours.
+    int held = 0;
+    double *next_out = traj + row0 * UAVAC_TRAJ_COLS;        // first element not yet stored
     int s = 0;
     for (int c0 = 0; c0 < N; c0 += SB) {
         const int r = c0 + lane;
@@ -163,6 +171,10 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             // (same wave, same addresses, program order => the later store wins)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // those rows' own stores have landed (once per mission at most)
             for (int i = lane; i < c0; i += SB) traj[(row0 + i) * UAVAC_TRAJ_COLS + 9] = first_yaw;
+            if (lane < 2 && c0 - 1 - lane >= 0) {             // ... and in what is still held back in LDS (at most two rows reach into it)
+                const long rel = (traj + (row0 + c0 - 1 - lane) * UAVAC_TRAJ_COLS + 9) - next_out;
+                if (rel >= 0 && rel < held) stage[rel] = first_yaw;
+            }
             if (yaw_dense) {
                 const int flushed = (c0 / (kYawGroup * SB)) * (kYawGroup * SB);      // rows already written from ybuf
                 for (int i = lane; i < flushed; i += SB) yaw_dense[row0 + i] = first_yaw;
@@ -191,16 +203,19 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             }
         }
         if (active) {
-            double *o = stage + lane * UAVAC_TRAJ_COLS;
+            double *o = stage + held + lane * UAVAC_TRAJ_COLS;
             o[0] = px; o[1] = py; o[2] = pz; o[3] = vx; o[4] = vy; o[5] = vz;
             o[6] = ax; o[7] = ay; o[8] = az; o[9] = yaw; o[10] = (double)s;
         }
         lds_wave_fence();                         // single wave: orders the LDS writes before the reads below
 
-        // coalesced write-out of the staged chunk: 16-byte stores from an even element index
+        // coalesced write-out: what was held back + this chunk, up to the last 128-byte line boundary (everything at the end
+        // of the mission), as 16-byte stores from an even element index
         const int nrows = min(SB, N - c0);
-        const int nel = nrows * UAVAC_TRAJ_COLS;
-        double *dst = traj + (row0 + c0) * UAVAC_TRAJ_COLS;
+        const int have = held + nrows * UAVAC_TRAJ_COLS;
+        double *dst = next_out;
+        const int beyond = (int)((reinterpret_cast<uintptr_t>(dst + have) >> 3) & 15);      // doubles past the last line boundary
+        const int nel = (c0 + SB >= N || beyond >= have) ? have : have - beyond;
         const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
         if (head && lane == 0) dst[0] = stage[0];
         const int npairs = (nel - head) >> 1;
@@ -211,7 +226,12 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             *reinterpret_cast<double2 *>(dst + head + 2 * p) = v;
         }
         if (((nel - head) & 1) && lane == 63) dst[nel - 1] = stage[nel - 1];
+        const int rest = have - nel;                                 // < 16: moves to the front of the stage
+        const double keep = (lane < rest) ? stage[nel + lane] : 0.0;
         lds_wave_fence();                         // the staged chunk is in registers / on its way; its stores stay in flight
+        if (lane < rest) stage[lane] = keep;
+        held = rest;
+        next_out = dst + nel;
     }
     if (first_yaw_out && lane == 0) first_yaw_out[b] = mission_first_yaw;
 }
@@ -255,7 +275,7 @@ int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg
     // Dense yaw column: 8 chunks (4 KB) leave together.  Measured for the bench's plan on a typical box of the pool, rows +
     // column / rows only: 1 chunk 1.84 / 1.52 ms, 4 chunks 1.77, 8 chunks 1.66, 16 chunks 1.68 (LDS then costs occupancy).
     const int yg = (plain && (ctx->yaw_group == 1 || ctx->yaw_group == 4 || ctx->yaw_group == 16)) ? ctx->yaw_group : 8;
-    size_t lds = sizeof(double) * ((size_t)SB * UAVAC_TRAJ_COLS + (size_t)24 * m) + sizeof(int) * (size_t)((m + 2 + 1) & ~1) +
+    size_t lds = sizeof(double) * ((size_t)kStageDoubles + (size_t)24 * m) + sizeof(int) * (size_t)((m + 2 + 1) & ~1) +
                  (x.yaw_dense ? sizeof(double) * yg * SB : 0);
     const bool hits = x.aabb && x.hit, derivs = x.jerk || x.snap;
     if (hits) UAVAC_HIP(ctx, hipMemsetAsync(x.hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
