@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD) ? 64 * SW : 
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
                        double *__restrict__ state_log, double *__restrict__ cmd_log,
-                       const double *__restrict__ aabbs, int n_obs, int col_base, const PlanRef P) {
+                       const double *__restrict__ aabbs, int n_obs, int col_base, const PlanRef P, int late_handover) {
     constexpr bool LOGGING = LOG_STATE || LOG_CMD;
     constexpr int NU = 64 * CW;                                        // UAVs per workgroup
     constexpr int NR = (LOG_STATE ? 13 : 0) + (LOG_CMD ? UAVAC_CMD_COLS : 0);
@@ -351,6 +351,9 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         body_rate(V, pc, qc, rc, wp, wq, wr, Mx, My, Mz);
         allocate(V, thrust_cmd, Mx, My, Mz, f);
         motors(V, f, om, omc);
+        // late hand-over: slab k-1 goes to the store wave HERE, a third of a tick after it was written -- the barrier's wait for
+        // this wave's LDS writes then finds nothing outstanding (the launcher says when that pays)
+        if (LOGGING && late_handover && k > 0) lds_barrier();
 
         double *my = LOGGING ? slab + (size_t)(k & 1) * NR * NU + tid : nullptr;
         if (LOG_CMD) {
@@ -379,10 +382,11 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             my[7 * NU] = vx; my[8 * NU] = vy; my[9 * NU] = vz;
             my[10 * NU] = wp; my[11 * NU] = wq; my[12 * NU] = wr;
         }
-        if (LOGGING) lds_barrier();        // hand slab k&1 to the store wave; it was drained two ticks ago
+        if (LOGGING && !late_handover) lds_barrier();        // hand slab k&1 to the store wave; it was drained two ticks ago
         ++inner;
         phase = (phase + 1 == V.F) ? 0 : phase + 1;
     }
+    if (LOGGING && late_handover && K > 0) lds_barrier();      // the last slab
 
     if (!POLY && nrows > 0) row_wait(nxt);          // nothing may stay in flight into these registers
     if (!live) return;
@@ -461,10 +465,14 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     for (int base = 0; base < B; base += per_launch) {
         const int cols = (B - base < per_launch) ? B - base : per_launch;
         const int grid = (cols + NU - 1) / NU;
+        // Hand the slab over at the end of the tick, or a third of a tick later (after the next tick's motor model)?  Results
+        // are the same bit for bit; per 1 000 logged ticks, end-of-tick / late: 0.905 / 0.880 ms at 8 192 and 16 384 columns,
+        // 0.979 / 0.985 at 24 576, 0.996 / 1.044 at 32 768, 1.16 / 1.11-1.14 at 49 152, 1.33 / 1.30 at 65 536.
+        const int late = (cols > 20480 && cols < 40960) ? 0 : 1;
         if (LOGGING && ctx->rollout_align)
             hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(128), 0, ctx->stream);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, V, traj, row_offsets, state, istate, B, K,
-                           state_log, cmd_log, aabbs, n_obs, base, P);
+                           state_log, cmd_log, aabbs, n_obs, base, P, late);
     }
     auto tf = [](bool v) { return v ? "true" : "false"; };
     char name[176];
