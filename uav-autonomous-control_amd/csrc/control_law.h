@@ -18,6 +18,16 @@ constexpr double kIntegralLimit = 10.0;     // CascadedController.INTEGRAL_ERROR
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
+// A constant that lives in a vector register.  fp64 literals that are not inline constants cannot be encoded in a vector
+// instruction: the compiler builds them in a scalar register pair (two s_mov_b32), and in the rollout's tick loop -- whose
+// ~50 vehicle constants already overflow the scalar file, at the price of v_readlane / v_writelane spills inside the loop --
+// it rebuilds them on every tick.  Laundered through an empty (non-volatile, hoistable) asm they are loaded once, ahead of the
+// loop, and cost nothing per tick.  Same value, same arithmetic: results cannot change.
+__device__ __forceinline__ double vk(double x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
 // Python's float `%` for a positive divisor (controller.py:173,178)
 __device__ __forceinline__ double floored_mod(double a, double b) {
     double r = fmod(a, b);
@@ -47,7 +57,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // sqrt(x) for x >= 0: Goldschmidt step on the rsq seed + one residual correction.  x is floored at the
 // smallest normal so that x == 0 needs no special case (returns 1.5e-154 instead of 0).
 __device__ __forceinline__ double fast_sqrt(double x) {
-    x = fmax(x, 2.2250738585072014e-308);
+    x = fmax(x, vk(2.2250738585072014e-308));
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
@@ -231,10 +241,10 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
     const double w2 = fma(wp, wp, fma(wq, wq, wr * wr));
     const double h2 = 0.25 * V.dt * V.dt * w2;
     double ch, sh_over;                           // cos(h), sin(h)/|w| = (dt/2) sinc(h)
-    if (h2 < 1.0e-3) {
+    if (h2 < vk(1.0e-3)) {
         // |h| < 0.0316 (|w| < 63 rad/s at dt = 1 ms): Taylor series through h^8, truncation < 3e-22
-        ch = fma(h2, fma(h2, fma(h2, fma(h2, 1.0 / 40320, -1.0 / 720), 1.0 / 24), -0.5), 1.0);
-        const double sinc = fma(h2, fma(h2, fma(h2, fma(h2, 1.0 / 362880, -1.0 / 5040), 1.0 / 120), -1.0 / 6), 1.0);
+        ch = fma(h2, fma(h2, fma(h2, fma(h2, vk(1.0 / 40320), vk(-1.0 / 720)), vk(1.0 / 24)), -0.5), 1.0);
+        const double sinc = fma(h2, fma(h2, fma(h2, fma(h2, vk(1.0 / 362880), vk(-1.0 / 5040)), vk(1.0 / 120)), vk(-1.0 / 6)), 1.0);
         sh_over = 0.5 * V.dt * sinc;
     } else {
         const double wn = sqrt(w2), h = 0.5 * V.dt * wn;
@@ -250,8 +260,8 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
     // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 is exact to rounding; a non-unit q (first tick of a caller-supplied
     // state) takes the general path.
     const double e = fma(n0, n0, fma(n1, n1, fma(n2, n2, n3 * n3))) - 1.0;
-    double inv = fma(e, fma(e, 0.375, -0.5), 1.0);
-    if (fabs(e) > 1.0e-6) inv = fast_rsqrt(e + 1.0);
+    double inv = fma(e, fma(e, vk(0.375), -0.5), 1.0);
+    if (fabs(e) > vk(1.0e-6)) inv = fast_rsqrt(e + 1.0);
     q0 = n0 * inv; q1 = n1 * inv; q2 = n2 * inv; q3 = n3 * inv;
 }
 

@@ -293,6 +293,13 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     const double qn2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
     double inv_n2 = (fabs(qn2 - 1.0) < 1.0e-12) ? 1.0 : 1.0 / qn2;
 
+    // The constants of the per-tick path, in vector registers (see vk() in control_law.h): with all of VehK in scalar
+    // registers the tick loop spilled SGPRs to VGPR lanes (v_readlane / v_writelane, 22 per tick) and rebuilt its fp64
+    // literals on every tick (60 s_mov_b32).  The outer block keeps reading its own constants from the kernel arguments.
+    VehK L = V;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { L.I[i] = vk(V.I[i]); L.inv_I[i] = vk(V.inv_I[i]); L.ikp[i] = vk(V.ikp[i]); }
+
     for (int k = 0; k < K; ++k) {
         if (phase == 0 && nrows > 0) {
             // ------------------------------------------------------------- outer loop (main.py:47-61)
@@ -348,9 +355,9 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 
         // ----------------------------------------------------------------- inner loop, every tick
         double Mx, My, Mz, f[4];
-        body_rate(V, pc, qc, rc, wp, wq, wr, Mx, My, Mz);
-        allocate(V, thrust_cmd, Mx, My, Mz, f);
-        motors(V, f, om, omc);
+        body_rate(L, pc, qc, rc, wp, wq, wr, Mx, My, Mz);
+        allocate(L, thrust_cmd, Mx, My, Mz, f);
+        motors(L, f, om, omc);
         // late hand-over: slab k-1 goes to the store wave HERE, a third of a tick after it was written -- the barrier's wait for
         // this wave's LDS writes then finds nothing outstanding (the launcher says when that pays)
         if (LOGGING && late_handover && k > 0) lds_barrier();
@@ -363,9 +370,9 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             for (int i = 0; i < 4; ++i) { c[(4 + i) * NU] = omc[i]; c[(8 + i) * NU] = om[i]; }
         }
 
-        free_body_step<GROUND>(V, om, px, py, pz, q0, q1, q2, q3, vx, vy, vz, wp, wq, wr, inv_n2);
+        free_body_step<GROUND>(L, om, px, py, pz, q0, q1, q2, q3, vx, vy, vz, wp, wq, wr, inv_n2);
         inv_n2 = 1.0;
-        if (GROUND) gbits = ground_bits(V, pz, gbits);
+        if (GROUND) gbits = ground_bits(L, pz, gbits);
 
         if (AABB && !(LOG_STATE && CW == SW)) {            // with a state log the store wave tests the logged positions
             for (int o = 0; o < n_obs; ++o) {

@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libuavac.so")
+# UAVAC_LIB: another build of the same ABI (development: A/B of two builds on one box, tools/)
+LIB_PATH = os.environ.get("UAVAC_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libuavac.so")
 
 OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
