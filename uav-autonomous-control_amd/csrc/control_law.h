@@ -28,9 +28,14 @@ __device__ __forceinline__ double vk(double x) {
     return x;
 }
 
-// Python's float `%` for a positive divisor (controller.py:173,178)
+// Python's float `%` for a positive divisor (controller.py:173,178): fmod, then + b when the remainder is negative.
+// fmod is exact, so in the two ranges the yaw law lives in its value is known without the (long, iterative) fp64 fmod:
+// |a| < b -> a itself; b <= a < 2b -> a - b, which is exact too (Sterbenz: b/2 <= a <= 2b).  Anything else takes fmod.
 __device__ __forceinline__ double floored_mod(double a, double b) {
-    double r = fmod(a, b);
+    double r;
+    if (fabs(a) < b) r = a;
+    else if (a >= b && a < 2.0 * b) r = a - b;
+    else r = fmod(a, b);
     if (r != 0.0 && r < 0.0) r += b;
     return r;
 }

@@ -299,6 +299,8 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     VehK L = V;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { L.I[i] = vk(V.I[i]); L.inv_I[i] = vk(V.inv_I[i]); L.ikp[i] = vk(V.ikp[i]); }
+    L.arm = vk(V.arm); L.inv_arm = vk(V.inv_arm); L.kappa = vk(V.kappa); L.inv_kappa = vk(V.inv_kappa);
+    L.kf = vk(V.kf); L.inv_kf = vk(V.inv_kf);
 
     for (int k = 0; k < K; ++k) {
         if (phase == 0 && nrows > 0) {
