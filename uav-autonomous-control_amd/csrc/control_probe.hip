@@ -249,7 +249,7 @@ struct uavac_pilot {
     int64_t *d_offsets = nullptr;
     double *d_aabbs = nullptr;
     int n_obs = 0;
-    double *h_state = nullptr;       // pinned + mapped: [26][B]
+    double *h_state = nullptr;       // pinned + mapped: [UAVAC_STATE_ROWS][B]
     int32_t *h_istate = nullptr;     // pinned + mapped: [4][B]
 };
 
