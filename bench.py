@@ -47,7 +47,7 @@ VELOCITY, DT, F = 3.0, 0.01, 10
 FP64_WAVE_INSTR_PEAK = 39.3e12 / 64  # vector fp64 peak of MI355X_MICROARCH.md: 78.6 TFLOP/s = 39.3 T lane-FMA/s = 614 G wave-instr/s
 GATHER_TIMEOUT_S = 240
 C4_TOTAL, C4_SEGMENTS, C4_TICKS = 262144, 8, 5000           # BASELINE.json configs[3]
-ROLLOUT_SOURCES = ("csrc/control_rollout.hip", "csrc/control_law.h", "csrc/minsnap_eval.h", "csrc/uavac_internal.h")
+ROLLOUT_SOURCES = ("csrc/control_rollout.hip", "csrc/control_law.h", "csrc/minsnap_eval.h", "csrc/minsnap_yaw.h", "csrc/uavac_internal.h")
 
 
 def missions(B_total, m, lo, hi):
