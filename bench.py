@@ -138,11 +138,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # UAVAC_BENCH_REHEARSAL=1: several ranks share one GPU (RCCL refuses that), the process group is gloo and the gather
+    # takes the host path of uav_ac.fleet.gather_rows on a slice of the rows.  It exists to walk the N > 1 control flow of
+    # this file on a 1-GPU box; its numbers mean nothing and the line says so.  The driver's runs never set it.
+    rehearsal = world > 1 and os.environ.get("UAVAC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if rehearsal else dev       # where the tensors of the (tiny) collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # barrier + max-over-ranks only; the gather has its own comm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # barrier + max-over-ranks only; the gather has its own comm
 
     B, m = args.batch, SEGMENTS
     eng = Engine(dev)
@@ -181,7 +191,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     flags = eng.take_flags()
@@ -239,6 +249,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            **({"REHEARSAL": "UAVAC_BENCH_REHEARSAL=1: ranks share one GPU; not a measurement"} if rehearsal else {}),
             "config": {"workload": "BASELINE.json configs[2]: batch 65536 UAVs/GPU, 12-segment missions with start/end "
                                    "time factor 1.5, min-snap solve+sample then 10000 fused controller+dynamics ticks "
                                    "(10 launches x 1000 ticks, 13-f64 state logged every tick)",
@@ -335,7 +346,7 @@ def main():
         barrier()
         c4_compute = (time.perf_counter() - t0) / n4
         if world > 1:
-            t = torch.tensor([c4_compute], dtype=torch.float64, device=dev)
+            t = torch.tensor([c4_compute], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c4_compute = float(t.item())
         c4 = {"workload": "BASELINE.json configs[3]: 262144 UAVs in total (strong scaling), 8-segment missions, plan + "
@@ -357,15 +368,27 @@ def main():
             watchdog.daemon = True
             watchdog.start()
             try:
-                comm = RcclComm(eng)                       # ncclCommInitRank behind the C ABI; id travels over the process group
-                comm.gather_rows(plan4.traj[:1024], dst=0)      # connection set-up is not part of the timed gather
-                barrier()
-                g0 = time.perf_counter()
-                gathered, counts = comm.gather_rows(plan4.traj, dst=0)
-                barrier()
-                gather_s = time.perf_counter() - g0
+                if rehearsal:
+                    from uav_ac.fleet import gather_rows
+                    mine = plan4.traj[:200000].cpu()           # a slice through gloo: control flow only
+                    barrier()
+                    g0 = time.perf_counter()
+                    gathered, counts = gather_rows(mine, dst=0)
+                    barrier()
+                    gather_s = time.perf_counter() - g0
+                    if rank == 0:
+                        gathered = gathered.to(dev)
+                else:
+                    comm = RcclComm(eng)                   # ncclCommInitRank behind the C ABI; id travels over the process group
+                    comm.gather_rows(plan4.traj[:1024], dst=0)      # connection set-up is not part of the timed gather
+                    barrier()
+                    g0 = time.perf_counter()
+                    gathered, counts = comm.gather_rows(plan4.traj, dst=0)
+                    barrier()
+                    gather_s = time.perf_counter() - g0
                 if rank == 0:
-                    ok = sum(counts) == gathered.shape[0] and bool((gathered[:plan4.total_rows] == plan4.traj).all())
+                    own = counts[0]
+                    ok = sum(counts) == gathered.shape[0] and bool((gathered[:own] == plan4.traj[:own]).all())
                     # every peer's block starts with its first mission's first waypoint, at rest
                     offs = np.concatenate([[0], np.cumsum(counts)])
                     first = missions(C4_TOTAL, C4_SEGMENTS, 0, C4_TOTAL)[::B4, 0, :]
@@ -373,6 +396,8 @@ def main():
                     ok = ok and bool(np.array_equal(got, first))
                     if not ok:
                         gather_err = "gathered rows do not match"
+                    if rehearsal:
+                        c4["REHEARSAL"] = "ranks share one GPU, gloo, a 200000-row slice per rank: control flow only, not a measurement"
                     c4.update({"gather_ms": gather_s * 1e3, "gather_rows_total": int(sum(counts)),
                                "gather_GBps_into_root": (sum(counts) - counts[0]) * 88 / gather_s / 1e9,
                                "steps_per_s_with_gather": C4_TOTAL * C4_TICKS / (c4_compute + gather_s),
@@ -395,7 +420,7 @@ def main():
             sys.exit(3)
 
     if world > 1:                                     # every rank learns whether any rank failed
-        bad = torch.tensor([0 if gather_err is None else 1], dtype=torch.int32, device=dev)
+        bad = torch.tensor([0 if gather_err is None else 1], dtype=torch.int32, device=cdev)
         try:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if int(bad.item()) and gather_err is None:
