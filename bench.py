@@ -142,13 +142,21 @@ def main():
     # takes the host path of uav_ac.fleet.gather_rows on a slice of the rows.  It exists to walk the N > 1 control flow of
     # this file on a 1-GPU box; its numbers mean nothing and the line says so.  The driver's runs never set it.
     rehearsal = world > 1 and os.environ.get("UAVAC_BENCH_REHEARSAL") == "1"
+    # UAVAC_BENCH_FORCE_DIST=1 at world 1: take the N > 1 path anyway -- the RCCL process group, the communicator behind
+    # the C ABI and the gather (to this very rank) all run on one GPU.  tests/test_gpu_round2.py uses it; the line is
+    # marked.  The driver's runs never set it.
+    forced = world == 1 and os.environ.get("UAVAC_BENCH_FORCE_DIST") == "1"
+    multi = world > 1 or forced
     if rehearsal:
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if rehearsal else dev       # where the tensors of the (tiny) collectives live
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced:
+            for k, v in (("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -177,7 +185,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -190,7 +198,7 @@ def main():
         one_step(rec)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -250,6 +258,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             **({"REHEARSAL": "UAVAC_BENCH_REHEARSAL=1: ranks share one GPU; not a measurement"} if rehearsal else {}),
+            **({"FORCED_DIST": "UAVAC_BENCH_FORCE_DIST=1: the N > 1 path (RCCL process group, communicator, gather) at world 1"}
+               if forced else {}),
             "config": {"workload": "BASELINE.json configs[2]: batch 65536 UAVs/GPU, 12-segment missions with start/end "
                                    "time factor 1.5, min-snap solve+sample then 10000 fused controller+dynamics ticks "
                                    "(10 launches x 1000 ticks, 13-f64 state logged every tick)",
@@ -345,7 +355,7 @@ def main():
             step4()
         barrier()
         c4_compute = (time.perf_counter() - t0) / n4
-        if world > 1:
+        if multi:
             t = torch.tensor([c4_compute], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c4_compute = float(t.item())
@@ -357,7 +367,7 @@ def main():
         if rank == 0:
             out["config4"] = c4
 
-        if world > 1:
+        if multi:
             def bail():
                 # a stalled exchange must not lose the measurement -- and must not look like a success either
                 if rank == 0:
@@ -408,7 +418,7 @@ def main():
             watchdog.cancel()
 
     def leave():
-        if world > 1:
+        if multi:
             if gather_err is None:
                 if comm is not None:
                     comm.close()
@@ -419,7 +429,7 @@ def main():
         if gather_err is not None:
             sys.exit(3)
 
-    if world > 1:                                     # every rank learns whether any rank failed
+    if multi:                                     # every rank learns whether any rank failed
         bad = torch.tensor([0 if gather_err is None else 1], dtype=torch.int32, device=cdev)
         try:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)

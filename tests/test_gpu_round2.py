@@ -26,6 +26,25 @@ def eng():
 
 
 # ------------------------------------------------------------------------------------------- RCCL behind the C ABI
+def test_bench_multi_gpu_path_on_real_rccl_at_world_1():
+    """bench.py's N > 1 code with WORLD_SIZE = 1 (UAVAC_BENCH_FORCE_DIST=1): torch's RCCL process group with a device id,
+    barrier and max-reduction on GPU tensors, the unique id broadcast over that group, ncclCommInitRank behind the C ABI,
+    the config-4 leg at its full 262 144 UAVs with the gather timed and verified, orderly shut-down, exit code 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UAVAC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "gather_error" not in line and "FORCED_DIST" in line and line["n_gpus"] == 1
+    c4 = line["config4"]
+    assert c4["batch_total"] == 262144 and c4["batch_per_gpu"] == 262144 and c4["gather_verified"] is True
+    assert c4["gather_rows_total"] == c4["rows_rank0"] and c4["gather_ms"] > 0
+
+
 def test_rccl_world1_gather_and_loopback(eng, nat):
     """ncclCommInitRank / ncclAllGather / ncclSend + ncclRecv through libuavac.so on one GPU: the calls of the
     8-GPU gather with world = 1 (the root's own block) and with this rank as its own peer (loopback)."""
