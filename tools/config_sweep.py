@@ -28,4 +28,11 @@ for name, B, m, K, aabb in (("config2", 4096, 8, 10000, None), ("config3", 65536
     print(json.dumps({"config": name, "B": B, "m": m, "ticks": K, "rows": plan.total_rows, "plan_ms": tp, "rollout_ms": tr,
                       "steps_per_s": B * K / (tr * 1e-3), "segments_per_s": B * m / (tp * 1e-3),
                       "collided": int(fleet.collided.sum()) if aabb is not None else None}))
+    if aabb is not None:                     # the same flight without a log: the obstacle test runs in the compute wave
+        def roll_nolog(ab):
+            fleet.reset()
+            for _ in range(K // 1000): fleet.rollout(1000, aabbs=ab)
+        t0, t1 = t(lambda: roll_nolog(None)), t(lambda: roll_nolog(aabb))
+        print(json.dumps({"config": name + " without a log", "rollout_ms_no_obstacles": t0, "rollout_ms": t1,
+                          "steps_per_s": B * K / (t1 * 1e-3), "collided": int(fleet.collided.sum())}))
     del plan, fleet, log

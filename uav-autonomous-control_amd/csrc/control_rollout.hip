@@ -145,6 +145,25 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         constexpr bool AABB_HERE = AABB && LOG_STATE && QPL == 1;
         const bool mine = col0 + lane < B;
         int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
+        // The first kBoxRegs obstacles live in vector registers for the whole launch (this wave has ~200 to spare: the
+        // kernel's allocation is sized by the compute wave).  Fetched through uniform addresses they would be scalar
+        // loads -- one s_load + s_waitcnt round trip per obstacle per TICK on the critical store stream.
+        constexpr int kBoxRegs = 8;
+        double box[kBoxRegs][6];
+        if (AABB_HERE) {
+            int zero = 0;
+            asm volatile("" : "+v"(zero));            // a per-lane offset the compiler cannot see through: vector loads
+#pragma unroll
+            for (int o = 0; o < kBoxRegs; ++o)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) box[o][j] = o < n_obs ? aabbs[6 * o + j + zero] : 0.0;
+            // the loads have landed before the tick loop starts: a load the compiler still sees in flight at the loop
+            // head costs an s_waitcnt vmcnt(0) at the first use in EVERY iteration, i.e. a wait for this wave's own stores
+#pragma unroll
+            for (int o = 0; o < kBoxRegs; ++o)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) settle(box[o][j]);
+        }
         for (int k = 0; k < K; ++k) {
             lds_barrier();                                             // slab k&1 is complete (stores of earlier ticks stay in flight)
             const double *src = slab + (size_t)(k & 1) * NR * NU + lane;
@@ -158,14 +177,22 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                     for (int q = 0; q < QPL; ++q) v[r][q] = src[r * NU + q * 64];
                 double *dst = state_log + (size_t)k * 13 * sB + col0;               // wave-uniform: lives in SGPRs
 #pragma unroll
-                for (int r = 0; r < 13; ++r)
+                for (int r = 0; r < 13; ++r) {
 #pragma unroll
                     for (int q = 0; q < QPL; ++q)
                         if (full || col0 + q * 64 + lane < B)                       // 512-B coalesced wave store
                             store_uniform_base(dst + r * sB + q * 64, lane_bytes, v[r][q]);
+                    // one obstacle between two stores: the comparisons issue while the store path takes the store
+                    if (AABB_HERE && r < kBoxRegs && r < n_obs) {
+                        const double x = v[0][0], y = v[1][0], z = v[2][0];
+                        const bool hit = (x >= box[r][0]) && (x <= box[r][1]) && (y >= box[r][2]) && (y <= box[r][3]) &&
+                                         (z >= box[r][4]) && (z <= box[r][5]);      // inclusive, minimum_snap.py:352-357
+                        coll |= hit ? 1 : 0;
+                    }
+                }
                 if (AABB_HERE) {
                     const double x = v[0][0], y = v[1][0], z = v[2][0];
-                    for (int o = 0; o < n_obs; ++o) {
+                    for (int o = kBoxRegs; o < n_obs; ++o) {      // more obstacles than registers hold: the slow way
                         const double *c = aabbs + 6 * o;          // uniform address: scalar loads
                         const bool hit = (x >= c[0]) && (x <= c[1]) && (y >= c[2]) && (y <= c[3]) && (z >= c[4]) &&
                                          (z <= c[5]);            // inclusive, minimum_snap.py:352-357
@@ -379,8 +406,11 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         if (AABB && !(LOG_STATE && CW == SW)) {            // with a state log the store wave tests the logged positions
             for (int o = 0; o < n_obs; ++o) {
                 const double *c = aabbs + 6 * o;          // uniform address: scalar loads
-                const bool hit = (px >= c[0]) && (px <= c[1]) && (py >= c[2]) && (py <= c[3]) && (pz >= c[4]) &&
-                                 (pz <= c[5]);            // inclusive, minimum_snap.py:352-357
+                // all six bounds first, then six comparisons combined without short-circuit: one scalar-cache round
+                // trip per obstacle (written with && it was one per BOUND: load, wait, compare, branch, six times)
+                const double x0 = c[0], x1 = c[1], y0 = c[2], y1 = c[3], z0 = c[4], z1 = c[5];
+                const bool hit = (px >= x0) & (px <= x1) & (py >= y0) & (py <= y1) & (pz >= z0) &
+                                 (pz <= z1);              // inclusive, minimum_snap.py:352-357
                 collided |= hit ? 1 : 0;
             }
         }
