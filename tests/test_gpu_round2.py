@@ -430,3 +430,26 @@ def test_plan_chain_edge_sizes_and_optional_outputs(eng, nat):
     s4 = d / T ** 4 * (840 - 10080 * t + 25200 * t ** 2 - 16800 * t ** 3)
     assert np.allclose(jerk[:, 0].cpu().numpy(), j, rtol=1e-9, atol=1e-9) and np.allclose(snap[:, 0].cpu().numpy(), s4, rtol=1e-9, atol=1e-9)
     assert float(jerk[:, 1:].abs().max()) < 1e-12 and float(snap[:, 1:].abs().max()) < 1e-12
+
+
+# ------------------------------------------------------------------------------------- many obstacles per tick
+@pytest.mark.parametrize("n_obs", [1, 8, 9, 10, 11, 14])
+def test_obstacle_flags_with_more_obstacles_than_registers_hold(eng, n_obs):
+    """The store wave keeps 8 obstacles in registers, the compute wave 10 in the lanes of one register pair; the rest take
+    the scalar-load path.  Only the LAST obstacle of the list is where vehicles fly (the others are far away), so a flag
+    can only come from the last slot of whichever path holds it: logged, unlogged and a recomputation from the log agree."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    B, K = 333, 1500
+    wps = mo.synthetic_missions(B, 4)
+    boxes = np.array([[100.0 + o, 101.0 + o, 100.0, 101.0, -50.0, -49.0] for o in range(n_obs)])
+    boxes[-1] = [0.0, 30.0, 0.0, 7.0, -3.5, -2.5]
+    logged, unlogged = (eng.fleet(eng.plan(wps, 3.0, 0.01)) for _ in range(2))
+    slog, _ = logged.rollout(K, state_log=True, aabbs=boxes)
+    unlogged.rollout(K, aabbs=boxes)
+    c = torch.as_tensor(boxes[-1], device=slog.device)
+    inside = ((slog[:, 0] >= c[0]) & (slog[:, 0] <= c[1]) & (slog[:, 1] >= c[2]) & (slog[:, 1] <= c[3]) &
+              (slog[:, 2] >= c[4]) & (slog[:, 2] <= c[5])).any(dim=0)
+    assert torch.equal(logged.collided.bool(), inside) and torch.equal(unlogged.collided.bool(), inside)
+    assert 0 < int(inside.sum()) < B
+    assert torch.equal(logged.state, unlogged.state)

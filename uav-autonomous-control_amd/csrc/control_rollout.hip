@@ -113,14 +113,19 @@ constexpr int poly_tile_doubles(bool yawscan) { return (24 + (yawscan ? 0 : 16))
 // first heading take P.first_yaw[b].  A cursor that does not match the carried scan (a caller moved it, another kernel
 // advanced it) is caught at launch and the scan is rebuilt from row 0.  No yaw bytes are read or written at all.
 template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN>
-__global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD) ? 64 * SW : 0))
+__global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD || AABB) ? 64 * SW : 0))
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
                        double *__restrict__ state_log, double *__restrict__ cmd_log,
                        const double *__restrict__ aabbs, int n_obs, int col_base, const PlanRef P, int late_handover) {
-    constexpr bool LOGGING = LOG_STATE || LOG_CMD;
+    // WATCH: obstacles but no log at all -- the second wave exists all the same and only WATCHES: it takes the three
+    // position values of every tick through the slab and tests them against obstacle bounds held in its registers.  In the
+    // compute wave the same test cost 0.4 us per tick for four obstacles (a scalar-cache round trip per obstacle on the
+    // one dependent instruction stream; bounds in lanes + v_readlane were slower still, and it has no registers to hold them).
+    constexpr bool WATCH = AABB && !LOG_STATE && !LOG_CMD && CW == SW;
+    constexpr bool LOGGING = LOG_STATE || LOG_CMD || WATCH;            // "a second wave takes a slab per tick"
     constexpr int NU = 64 * CW;                                        // UAVs per workgroup
-    constexpr int NR = (LOG_STATE ? 13 : 0) + (LOG_CMD ? UAVAC_CMD_COLS : 0);
+    constexpr int NR = (LOG_STATE ? 13 : 0) + (LOG_CMD ? UAVAC_CMD_COLS : 0) + (WATCH ? 3 : 0);
     constexpr int CMD0 = LOG_STATE ? 13 : 0;                           // first command row in a slab
     extern __shared__ double slab[];                                   // [2][NR][NU]
     const size_t sB = (size_t)B;
@@ -142,7 +147,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         // its stores have been issued: the compute wave's tick stays as short as without obstacles (the two stages
         // couple through one barrier per tick; lengthening the compute stage to the length of the store stage cost
         // 40 % at config 5), and the comparisons fill time in which this wave would wait for the store path anyway.
-        constexpr bool AABB_HERE = AABB && LOG_STATE && QPL == 1;
+        constexpr bool AABB_HERE = AABB && (LOG_STATE || WATCH) && QPL == 1;
         const bool mine = col0 + lane < B;
         int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
         // The first kBoxRegs obstacles live in vector registers for the whole launch (this wave has ~200 to spare: the
@@ -200,6 +205,21 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                     }
                 }
             }
+            if (WATCH) {
+                const double x = src[0], y = src[NU], z = src[2 * NU];
+#pragma unroll
+                for (int o = 0; o < kBoxRegs; ++o)
+                    if (o < n_obs) {
+                        const bool hit = (x >= box[o][0]) & (x <= box[o][1]) & (y >= box[o][2]) & (y <= box[o][3]) &
+                                         (z >= box[o][4]) & (z <= box[o][5]);       // inclusive, minimum_snap.py:352-357
+                        coll |= hit ? 1 : 0;
+                    }
+                for (int o = kBoxRegs; o < n_obs; ++o) {
+                    const double *c = aabbs + 6 * o;
+                    const double x0 = c[0], x1 = c[1], y0 = c[2], y1 = c[3], z0 = c[4], z1 = c[5];
+                    coll |= ((x >= x0) & (x <= x1) & (y >= y0) & (y <= y1) & (z >= z0) & (z <= z1)) ? 1 : 0;
+                }
+            }
             if (LOG_CMD) {
                 double v[UAVAC_CMD_COLS][QPL];
 #pragma unroll
@@ -253,6 +273,8 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 #pragma unroll
     for (int i = 0; i < 4; ++i) { settle(om[i]); settle(omc[i]); }
     settle(idx); settle(phase); settle(collided);
+
+    constexpr bool BOX_HERE = AABB && !((LOG_STATE || WATCH) && CW == SW);
 
     RowRegs nxt;
     if (!POLY && nrows > 0) row_issue(nxt, rows + (size_t)min(max(idx, 0), nrows - 1) * UAVAC_TRAJ_COLS);
@@ -403,7 +425,8 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         inv_n2 = 1.0;
         if (GROUND) gbits = ground_bits(L, pz, gbits);
 
-        if (AABB && !(LOG_STATE && CW == SW)) {            // with a state log the store wave tests the logged positions
+        if (WATCH) { my[0] = px; my[1 * NU] = py; my[2 * NU] = pz; }
+        if (BOX_HERE) {                                   // only with a command log alone; otherwise the second wave tests
             for (int o = 0; o < n_obs; ++o) {
                 const double *c = aabbs + 6 * o;          // uniform address: scalar loads
                 // all six bounds first, then six comparisons combined without short-circuit: one scalar-cache round
@@ -441,7 +464,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     state[23 * sB + b] = pc; state[24 * sB + b] = qc; state[25 * sB + b] = rc;
     istate[0 * sB + b] = idx;
     istate[1 * sB + b] = inner;
-    if (!(AABB && LOG_STATE && CW == SW)) istate[2 * sB + b] = collided;
+    if (!AABB || BOX_HERE) istate[2 * sB + b] = collided;
     if (GROUND) istate[3 * sB + b] = gbits;
     if (POLY && YAWSCAN) {
         state[26 * sB + b] = (double)idx;
@@ -490,9 +513,10 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
                   int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                   const PlanRef &P) {
     constexpr int CW = 1, SW = 1;
-    constexpr bool LOGGING = LS || LC;
+    constexpr bool WATCH = AB && !LS && !LC;           // obstacles without a log: the second wave only watches
+    constexpr bool LOGGING = LS || LC || WATCH;
     constexpr int NU = 64 * CW;
-    constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0);
+    constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0) + (WATCH ? 3 : 0);
     constexpr int threads = NU + (LOGGING ? 64 * SW : 0);
     const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0));
     auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS>;
