@@ -30,6 +30,7 @@ vg=re.findall(r"\.vgpr_count:\s+(\d+)", notes);
 idx=[m.start() for m in re.finditer(re.escape(name), notes)]
 seg=notes[max(0,idx[0]-1500):idx[0]+200]
 print(name[:70])
-print(' loop', hi-lo+1, 'outer', ohi-olo, 'inner', len(inner), '| inner: s_mov', c['s_mov_b32'], 'lane ops', sum(v for k,v in c.items() if 'lane' in k), 'valu', sum(v for k,v in c.items() if k.startswith('v_')), 'branches', sum(v for k,v in c.items() if 'branch' in k))
+print(' loop', hi-lo+1, 'outer', ohi-olo, 'inner', len(inner), '| inner: s_mov', c['s_mov_b32'], 'lane ops', sum(v for k,v in c.items() if 'lane' in k), 'valu', sum(v for k,v in c.items() if k.startswith('v_')), 'branches', sum(v for k,v in c.items() if 'branch' in k),
+      '| scalar loads', sum(v for k,v in c.items() if k.startswith('s_load')), 'waits', c['s_waitcnt'])
 print(' regs:', re.findall(r"\.(?:sgpr_count|sgpr_spill_count|vgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+\d+", seg)[-5:])
 shutil.rmtree(tmp)
