@@ -21,7 +21,8 @@
 //
 // HBM: the forward sweep parks [Ut_k | rt_k] (28 doubles per knot) in a [m-1][28][B] workspace (coalesced
 // across lanes) for the backward sweep; coefficients leave through a 64 x 24 LDS transpose so that the
-// reference's per-mission (8m, 3) layout is written in 192-byte runs.
+// reference's per-mission (8m, 3) layout is written in 192-byte runs.  Loads are issued a knot / segment ahead of
+// their use and ahead of that step's stores (see the kernel).
 
 #include "uavac_internal.h"
 
@@ -161,14 +162,23 @@ __device__ __forceinline__ void segment_coeffs(const double ip[8], double T, con
     }
 }
 
-constexpr int TB = 64;          // lanes (missions) per workgroup
+constexpr int TB = 64;          // lanes (missions) per workgroup = one wave
 
+// Memory discipline (gfx9 counts loads AND stores in vmcnt, and a wait cannot tell them apart): a wave that has stores in
+// flight pays their whole write latency at its next wait for a load.  So every load is issued a full knot / segment before
+// its use and BEFORE the stores of the step it is issued in: when the next step waits for it, the youngest stores in
+// flight are a step old.  Forward sweep, knot k: issue the loads of knot k + 1's inputs, compute, park 28 doubles.
+// Backward sweep, segment s: issue the coefficient stores of segment s + 1 (from the LDS stage) and the loads of knot
+// s - 2 and of segment s - 1's inputs, then compute segment s from what was loaded a segment ago.  (As first written --
+// inputs loaded where they were used, the parked block read in the compiler's order, four at a time between the FMAs --
+// the kernel took 160 us at B = 65 536, m = 12 for ~30 us of arithmetic.)  No workgroup barrier anywhere: one wave,
+// whose LDS operations execute in order (`lds_wave_fence`; `__syncthreads` would wait for the global stores too).
 __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__restrict__ wp,
                                                              const double *__restrict__ times, int B, int m,
                                                              double *__restrict__ ws, double *__restrict__ coeffs,
                                                              int32_t *__restrict__ status,
                                                              int32_t *__restrict__ flags) {
-    __shared__ double stage[TB][25];                  // one segment's 24 coefficients per mission (+1 pad)
+    __shared__ double stage[TB * 25];                 // one segment's 24 coefficients per mission (+1 pad)
     const int lane = threadIdx.x;
     const int b0 = blockIdx.x * TB;
     const int b = b0 + lane;
@@ -186,11 +196,20 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
         double Ut[4][4], rt[4][3];
         double p0[3] = {w[0], w[1], w[2]}, p1[3] = {w[3], w[4], w[5]};
         build_segment(prev, tm[0], p0, p1);
+        // inputs of the knot after this one (clamped reads past the end are never used)
+        double nw[3] = {w[6 <= 3 * m ? 6 : 3], w[6 <= 3 * m ? 7 : 4], w[6 <= 3 * m ? 8 : 5]}, nt = tm[m > 1 ? 1 : 0];
         for (int kk = 0; kk < nk; ++kk) {
             const int k = kk + 1;                      // knot k joins segments k-1 (prev) and k (cur)
+            const double T = nt;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { p0[a] = p1[a]; p1[a] = w[3 * (k + 1) + a]; }
-            build_segment(cur, tm[k], p0, p1);
+            for (int a = 0; a < 3; ++a) { p0[a] = p1[a]; p1[a] = nw[a]; }
+            {
+                const int kn = (k + 2 <= m) ? k + 2 : m, tn = (k + 1 <= m - 1) ? k + 1 : m - 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) nw[a] = w[3 * kn + a];
+                nt = tm[tn];
+            }
+            build_segment(cur, T, p0, p1);
             double S[4][4], R[4][7];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -246,18 +265,54 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
 #pragma unroll
         for (int a = 0; a < 3; ++a) xn[i][a] = 0.0;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    // 64 missions x 24 doubles of one segment leave the stage as 192-byte runs: mission q's run is at
+    // coeffs[(b0 + q) * 24 m + 24 s]
+    auto flush = [&](int s) {
+        for (int e = lane; e < TB * 24; e += TB) {
+            const int q = e / 24, j = e - q * 24;
+            if (b0 + q < B) coeffs[(size_t)(b0 + q) * 24 * m + 24 * s + j] = stage[q * 25 + j];
+        }
+    };
+    // on their way while the segment before is computed: [Ut | rt] of knot s - 1, start waypoint and duration of segment s
+    double nxt[28], nw[3], nt;
+    {
+        const double *o = ws + ((size_t)(nk >= 1 ? nk - 1 : 0) * 28) * sB + bb;
+        if (nk >= 1) {
+#pragma unroll
+            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * sB];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) nw[a] = w[3 * (m - 1) + a];
+        nt = tm[m - 1];
+    }
+    double p1[3] = {w[3 * m], w[3 * m + 1], w[3 * m + 2]};
     for (int s = m - 1; s >= 0; --s) {
+        double cur[28];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) cur[i] = nxt[i];   // (the first use waits for the loads -- and for stores issued a segment ago)
+        const double T = nt;
+        const double p0[3] = {nw[0], nw[1], nw[2]};
+        if (s + 1 <= m - 1) flush(s + 1);               // reads the stage before this segment overwrites it (LDS is in order)
+        if (s >= 2) {
+            const double *o = ws + ((size_t)(s - 2) * 28) * sB + bb;
+#pragma unroll
+            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * sB];
+        }
+        if (s >= 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) nw[a] = w[3 * (s - 1) + a];
+            nt = tm[s - 1];
+        }
         double xs[4][3];                                // unknowns of knot s (zero at the start)
         if (s >= 1) {
-            const double *o = ws + ((size_t)(s - 1) * 28) * sB + bb;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    double v = o[(size_t)(16 + i * 3 + a) * sB];
+                    double v = cur[16 + i * 3 + a];
                     if (s <= nk - 1) {                  // knot s has a successor among the unknowns
 #pragma unroll
-                        for (int l = 0; l < 4; ++l) v = fma(-o[(size_t)(i * 4 + l) * sB], xn[l][a], v);
+                        for (int l = 0; l < 4; ++l) v = fma(-cur[i * 4 + l], xn[l][a], v);
                     }
                     xs[i][a] = v;
                 }
@@ -267,9 +322,6 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
 #pragma unroll
                 for (int a = 0; a < 3; ++a) xs[i][a] = 0.0;
         }
-        const double T = tm[s];
-        const double p0[3] = {w[3 * s], w[3 * s + 1], w[3 * s + 2]};
-        const double p1[3] = {w[3 * s + 3], w[3 * s + 4], w[3 * s + 5]};
         double ip[8];
         const double r = 1.0 / T;
         ip[0] = 1.0;
@@ -279,22 +331,19 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
         const double x1[3][3] = {{xn[0][0], xn[0][1], xn[0][2]}, {xn[1][0], xn[1][1], xn[1][2]}, {xn[2][0], xn[2][1], xn[2][2]}};
         double c[8][3];
         segment_coeffs(ip, T, p0, p1, x0, x1, c);
-        __syncthreads();                                // previous segment's stage fully drained
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) stage[lane][i * 3 + a] = ok ? c[i][a] : qnan;
-        __syncthreads();
-        // 64 missions x 24 doubles: mission q's run is 192 contiguous bytes at coeffs[(b0+q)*24m + 24 s]
-        for (int e = lane; e < TB * 24; e += TB) {
-            const int q = e / 24, j = e - q * 24;
-            if (b0 + q < B) coeffs[(size_t)(b0 + q) * 24 * m + 24 * s + j] = stage[q][j];
-        }
+            for (int a = 0; a < 3; ++a) stage[lane * 25 + i * 3 + a] = ok ? c[i][a] : qnan;
+        lds_wave_fence();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int a = 0; a < 3; ++a) xn[i][a] = xs[i][a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p1[a] = p0[a];
     }
+    flush(0);
 }
 
 }  // namespace
