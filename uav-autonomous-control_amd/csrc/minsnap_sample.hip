@@ -136,6 +136,13 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     // written once, whole, by one run of stores; only a mission's first and last line are shared with its neighbours.
     int held = 0;
     double *next_out = traj + row0 * UAVAC_TRAJ_COLS;        // first element not yet stored
+    // the cuboid's bounds, read once (inside the chunk loop, written with &&, they were up to six dependent scalar-cache
+    // round trips per chunk: the atomic on `hit` keeps the compiler from hoisting them itself)
+    double box[6] = {0, 0, 0, 0, 0, 0};
+    if (HITS) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) box[j] = aabb[j];
+    }
     int s = 0;
     for (int c0 = 0; c0 < N; c0 += SB) {
         const int r = c0 + lane;
@@ -156,8 +163,8 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
         }
         if (HITS) {
             // inclusive AABB test on the sampled position (minimum_snap.py:327-357); flags the row's spline
-            const bool in = active && px >= aabb[0] && px <= aabb[1] && py >= aabb[2] && py <= aabb[3] &&
-                            pz >= aabb[4] && pz <= aabb[5];
+            const bool in = active & (px >= box[0]) & (px <= box[1]) & (py >= box[2]) & (py <= box[3]) &
+                            (pz >= box[4]) & (pz <= box[5]);
             if (in) atomicOr(&hit[(size_t)b * m + s], 1);
         }
         const bool valid = active && has_heading(vx, vy);
