@@ -145,15 +145,15 @@ int uavac_minsnap_solve_banded_dev(uavac_ctx *ctx, const double *wp, const doubl
 int uavac_minsnap_sample_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
                              const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                              double dt, double *traj);
-/* Sampler that also reports, per mission and spline, whether any sampled position lies inside the cuboid
- * aabb[6] = xmin xmax ymin ymax zmin zmax (device pointer; inclusive test of is_collision_cuboid :327-357):
- * hit [B][m] i32 (0/1).  This is the collision scan of _generate_collision_free_trajectory (:81-87), fused
- * into the sampling pass; the midpoint insertion that follows (:91-92) is host logic. */
 /* uavac_minsnap_sample_dev that also writes the yaw column on its own: yaw[row_offsets[B]]
  * (yaw[i] == traj[i][9]); input of uavac_control_rollout_plan_dev. */
 int uavac_minsnap_sample_yaw_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
                                  const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                                  double dt, double *traj, double *yaw);
+/* Sampler that also reports, per mission and spline, whether any sampled position lies inside the cuboid
+ * aabb[6] = xmin xmax ymin ymax zmin zmax (device pointer; inclusive test of is_collision_cuboid :327-357):
+ * hit [B][m] i32 (0/1).  This is the collision scan of _generate_collision_free_trajectory (:81-87), fused
+ * into the sampling pass; the midpoint insertion that follows (:91-92) is host logic. */
 int uavac_minsnap_sample_hits_dev(uavac_ctx *ctx, const double *coeffs, const double *times,
                                   const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                                   double dt, double *traj, const double *aabb, int32_t *hit);
@@ -178,6 +178,28 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
                            double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs,
                            int32_t *status, double *traj, int64_t traj_capacity_rows, double *yaw,
                            double *first_yaw);
+
+/* Ragged batches: missions with different numbers of waypoints in one call -- what a fleet of MinimumSnap objects with
+ * paths of different lengths is (minimum_snap.py:13-57 takes any path), and what the obstacle loop (:63-95) produces as
+ * soon as one mission has received a midpoint.  Mission b has m_b = seg_offsets[b+1] - seg_offsets[b] segments
+ * (1 <= m_b <= max_m <= UAVAC_MAX_SEGMENTS; seg_offsets [B+1] i64, device, seg_offsets[0] = 0) and m_b + 1 waypoints.
+ * Everything per-segment lies back to back in mission order: wp [S + B][3] (mission b starts at waypoint
+ * seg_offsets[b] + b), times / seg_rows / hit [S], coeffs [S][8][3], S = seg_offsets[B] = total_segments.
+ * Same kernels, same arithmetic: mission b's outputs equal those of a uniform call on it alone, bit for bit.
+ * A segment count outside 1 .. max_m raises sticky flag 0 (uavac_take_flags) and is clamped.  The sampler takes the
+ * capacity of the row buffer like uavac_minsnap_plan_dev (flag 2 and nothing written when it is too small; < 0: not
+ * checked), an optional cuboid + hit flags (both or neither) and optional first_yaw [B]. */
+int uavac_minsnap_row_counts_ragged_dev(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B,
+                                        int max_m, double velocity, double dt, double *times,
+                                        int32_t *seg_rows, int64_t *row_offsets);
+int uavac_minsnap_solve_ragged_dev(uavac_ctx *ctx, const double *wp, const double *times,
+                                   const int64_t *seg_offsets, int B, int max_m, double *coeffs,
+                                   int32_t *status);
+int uavac_minsnap_sample_ragged_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows,
+                                    const int64_t *seg_offsets, const int64_t *row_offsets, int B, int max_m,
+                                    int64_t total_segments, double dt, double *traj,
+                                    int64_t traj_capacity_rows, const double *aabb, int32_t *hit,
+                                    double *first_yaw);
 /* MinimumSnap._calculate_yaws (minimum_snap.py:126-136) on its own, for B independent velocity
  * sequences of any length: sequence b = rows [offsets[b], offsets[b+1]) of velocities[.][3] (only
  * vx, vy are read); yaws[offsets[B]].  Headings of rows with |v_xy| >= 1e-3, np.unwrap over those,

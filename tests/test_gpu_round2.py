@@ -453,3 +453,83 @@ def test_obstacle_flags_with_more_obstacles_than_registers_hold(eng, n_obs):
     assert torch.equal(logged.collided.bool(), inside) and torch.equal(unlogged.collided.bool(), inside)
     assert 0 < int(inside.sum()) < B
     assert torch.equal(logged.state, unlogged.state)
+
+
+# ------------------------------------------------------------------------------------- ragged batches
+def test_ragged_batch_equals_uniform_plans_bit_for_bit(eng, nat):
+    """Missions of different lengths in one call (uavac_minsnap_*_ragged_dev): every mission's durations, row counts,
+    coefficients, rows, first heading and status equal those of the uniform entry points on a batch of its own length --
+    same kernels, same arithmetic.  Lengths are mixed inside every wave of the lane-per-mission solver (1 .. 64 segments),
+    the batch ends in a ragged tail, and the per-spline hit flags equal a recomputation from the rows."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    lengths = [1, 2, 3, 5, 8, 12, 20, 33, 64]
+    rng = np.random.default_rng(7)
+    ms = rng.choice(lengths, size=203)
+    ms[:9] = lengths                                             # each length at least once
+    pools = {m: mo.synthetic_missions(int((ms == m).sum()), m) for m in lengths}
+    taken = {m: 0 for m in lengths}
+    missions, where = [], []
+    for m in ms:
+        missions.append(pools[m][taken[m]]); where.append((int(m), taken[m])); taken[m] += 1
+    cub = np.array([0.0, 30.0, 0.0, 7.0, -3.5, -2.5])
+    rb = eng.plan_ragged(missions, 3.0, 0.01, cuboid=cub)
+    assert rb.B == 203 and rb.max_m == 64 and int(rb.seg_offsets_host[-1]) == int(ms.sum())
+    uniform = {m: eng.plan(pools[m], 3.0, 0.01) for m in lengths}
+    ro = rb.row_offsets.cpu().numpy()
+    hit = rb.hit.cpu().numpy()
+    for b, (m, j) in enumerate(where):
+        u = uniform[m]
+        s0, s1 = int(rb.seg_offsets_host[b]), int(rb.seg_offsets_host[b + 1])
+        assert s1 - s0 == m
+        assert torch.equal(rb.times[s0:s1], u.times[j]) and torch.equal(rb.seg_rows[s0:s1], u.seg_rows[j])
+        assert torch.equal(rb.coeffs[s0:s1].reshape(-1, 3), u.coeffs[j])
+        uo = u.row_offsets[j:j + 2].cpu().numpy()
+        assert ro[b + 1] - ro[b] == uo[1] - uo[0]
+        rows = rb.traj[ro[b]:ro[b + 1]]
+        assert torch.equal(rows, u.traj[uo[0]:uo[1]])
+        assert float(rb.first_yaw[b]) == float(u.first_yaw[j])
+        inside = ((rows[:, 0] >= cub[0]) & (rows[:, 0] <= cub[1]) & (rows[:, 1] >= cub[2]) & (rows[:, 1] <= cub[3]) &
+                  (rows[:, 2] >= cub[4]) & (rows[:, 2] <= cub[5]))
+        want = np.zeros(m, dtype=bool)
+        want[np.unique(rows[inside][:, 10].cpu().numpy().astype(int))] = True
+        assert np.array_equal(hit[s0:s1].astype(bool), want), b
+    assert int(rb.status.sum()) == 0 and 0 < hit.sum() < len(hit)
+    assert eng.take_flags() == [0, 0, 0, 0]
+
+
+def test_ragged_entry_points_reject_bad_arguments(eng, nat):
+    import torch
+    from oracle import minsnap_oracle as mo
+    with pytest.raises(ValueError):
+        eng.plan_ragged([], 3.0, 0.01)
+    with pytest.raises(ValueError):
+        eng.plan_ragged([np.zeros((1, 3))], 3.0, 0.01)             # a path needs two waypoints
+    with pytest.raises(ValueError):
+        eng.plan_ragged([np.zeros((nat.MAX_SEGMENTS + 2, 3))], 3.0, 0.01)
+    rb = eng.plan_ragged([mo.synthetic_missions(1, 3)[0], mo.synthetic_missions(1, 5)[0]], 3.0, 0.01)
+    P = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    def code(fn, *a):
+        with pytest.raises(nat.UavacError) as e:
+            eng.ctx.call(fn, *a)
+        return e.value.code
+    assert code("uavac_minsnap_row_counts_ragged_dev", P(rb.waypoints), P(None), 2, 5, 3.0, 0.01, P(rb.times), P(rb.seg_rows),
+                P(rb.row_offsets)) == nat.EINVAL
+    assert code("uavac_minsnap_row_counts_ragged_dev", P(rb.waypoints), P(rb.seg_offsets), 2, 65, 3.0, 0.01, P(rb.times),
+                P(rb.seg_rows), P(rb.row_offsets)) == nat.EINVAL
+    assert code("uavac_minsnap_solve_ragged_dev", P(rb.waypoints), P(rb.times), P(None), 2, 5, P(rb.coeffs), P(None)) == nat.EINVAL
+    args = [P(rb.coeffs), P(rb.seg_rows), P(rb.seg_offsets), P(rb.row_offsets), 2, 5, 8, 0.01, P(rb.traj), rb.total_rows]
+    assert code("uavac_minsnap_sample_ragged_dev", *args, P(rb.first_yaw), P(None), P(None)) == nat.EINVAL     # cuboid without flags
+    args[6] = 1                                                                                               # fewer segments than missions
+    assert code("uavac_minsnap_sample_ragged_dev", *args, P(None), P(None), P(None)) == nat.EINVAL
+    # a segment count beyond max_m is clamped and reported by the sticky flag, never followed out of bounds
+    eng.take_flags()
+    eng.ctx.call("uavac_minsnap_row_counts_ragged_dev", P(rb.waypoints), P(rb.seg_offsets), 2, 4, 3.0, 0.01, P(rb.times),
+                 P(rb.seg_rows), P(rb.row_offsets))
+    assert eng.take_flags()[0] == 1
+    # a row buffer that is too small: nothing is written, flag 2
+    small = torch.zeros((10, nat.TRAJ_COLS), dtype=torch.float64, device=eng.device)
+    rb2 = eng.plan_ragged([mo.synthetic_missions(1, 3)[0]], 3.0, 0.01)
+    eng.ctx.call("uavac_minsnap_sample_ragged_dev", P(rb2.coeffs), P(rb2.seg_rows), P(rb2.seg_offsets), P(rb2.row_offsets), 1, 3,
+                 3, 0.01, P(small), 10, P(None), P(None), P(None))
+    assert eng.take_flags()[2] == 1 and float(small.abs().sum()) == 0.0

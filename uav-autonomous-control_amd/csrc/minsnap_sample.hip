@@ -86,7 +86,9 @@ __device__ __forceinline__ double yaw_chunk(bool valid, double ang, int lane, Ya
 // (minimum_snap.py:111-112,118-119: polynom(8, 3 | 4, t) @ coeffs); separate arrays, never extra row columns.
 // capacity_rows >= 0: the row buffer holds that many rows; a plan that needs more is refused as a whole (flag 2).
 // YG: chunks whose dense-column yaws leave together (LDS buffer of YG * 64 doubles per wave).
-template <bool HITS, bool DERIVS, int kYawGroup>
+// RAGGED: mission b has seg_offsets[b + 1] - seg_offsets[b] segments (clamped to 1 .. m, m = the batch's maximum, which sizes
+// the LDS); coefficients, row counts and hit flags of the batch lie back to back.
+template <bool HITS, bool DERIVS, int kYawGroup, bool RAGGED = false>
 __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__restrict__ coeffs,
                                                            const int32_t *__restrict__ seg_rows,
                                                            const int64_t *__restrict__ row_offsets, int B, int m,
@@ -94,7 +96,8 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
                                                            const double *__restrict__ aabb, int32_t *__restrict__ hit,
                                                            double *__restrict__ yaw_dense, double *__restrict__ jerk,
                                                            double *__restrict__ snap, int64_t capacity_rows,
-                                                           int32_t *__restrict__ flags, double *__restrict__ first_yaw_out) {
+                                                           int32_t *__restrict__ flags, double *__restrict__ first_yaw_out,
+                                                           const int64_t *__restrict__ seg_offsets) {
     extern __shared__ double lds[];
     double *stage = lds;                         // [kCarryMax + SB*11]: what is left of the previous chunk, then this chunk
     double *cl = stage + kStageDoubles;          // [24*m] coefficients of this mission
@@ -112,17 +115,24 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
         return;
     }
 
-    for (int i = lane; i < 24 * m; i += SB) cl[i] = coeffs[(size_t)b * 24 * m + i];
+    int mb = m;                                   // segments of this mission, and where they start in the batch
+    size_t seg0 = (size_t)b * m;
+    if (RAGGED) {
+        seg0 = (size_t)seg_offsets[b];
+        const int64_t n = seg_offsets[b + 1] - seg_offsets[b];
+        mb = (int)(n < 1 ? 1 : (n > m ? m : n));
+    }
+    for (int i = lane; i < 24 * mb; i += SB) cl[i] = coeffs[seg0 * 24 + i];
     {   // exclusive prefix of the per-segment row counts: lane s holds segment s (m <= 64)
-        int v = (lane < m) ? seg_rows[(size_t)b * m + lane] : 0;
+        int v = (lane < mb) ? seg_rows[seg0 + lane] : 0;
         int inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(inc, d);
             if (lane >= d) inc += o;
         }
-        if (lane < m) pre[lane] = inc - v;
-        if (lane == m - 1) pre[m] = inc;
+        if (lane < mb) pre[lane] = inc - v;
+        if (lane == mb - 1) pre[mb] = inc;
     }
     __syncthreads();
 
@@ -149,7 +159,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
         const bool active = r < N;
         double px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0, ax = 0, ay = 0, az = 0;
         if (active) {
-            s = segment_of(pre, m, r, s);
+            s = segment_of(pre, mb, r, s);
             const double t = (double)(r - pre[s]) * dt;
             const double *c = cl + s * 24;
             minsnap_eval_row<1>(c, t, px, py, pz, vx, vy, vz, ax, ay, az);
@@ -165,7 +175,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             // inclusive AABB test on the sampled position (minimum_snap.py:327-357); flags the row's spline
             const bool in = active & (px >= box[0]) & (px <= box[1]) & (py >= box[2]) & (py <= box[3]) &
                             (pz >= box[4]) & (pz <= box[5]);
-            if (in) atomicOr(&hit[(size_t)b * m + s], 1);
+            if (in) atomicOr(&hit[seg0 + s], 1);
         }
         const bool valid = active && has_heading(vx, vy);
         const double ang = valid ? atan2(vy, vx) : 0.0;
@@ -285,11 +295,24 @@ int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg
     size_t lds = sizeof(double) * ((size_t)kStageDoubles + (size_t)24 * m) + sizeof(int) * (size_t)((m + 2 + 1) & ~1) +
                  (x.yaw_dense ? sizeof(double) * yg * SB : 0);
     const bool hits = x.aabb && x.hit, derivs = x.jerk || x.snap;
-    if (hits) UAVAC_HIP(ctx, hipMemsetAsync(x.hit, 0, sizeof(int32_t) * (size_t)B * m, ctx->stream));
+    const bool ragged = x.seg_offsets != nullptr;
+    if (ragged && (derivs || x.yaw_dense || x.total_segments < 0))
+        return uavac_fail(ctx, UAVAC_EINVAL, "ragged sampling: rows (+ hit flags, first yaws) only, and the segment total");
+    if (hits)
+        UAVAC_HIP(ctx, hipMemsetAsync(x.hit, 0, sizeof(int32_t) * (ragged ? (size_t)x.total_segments : (size_t)B * m), ctx->stream));
 #define UAVAC_SAMPLE(H, D, Y)                                                                                          \
     hipLaunchKernelGGL((minsnap_sample_kernel<H, D, Y>), dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows, row_offsets, \
-                       B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags, x.first_yaw)
-    if (hits) { if (derivs) UAVAC_SAMPLE(true, true, 8); else UAVAC_SAMPLE(true, false, 8); }
+                       B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags, x.first_yaw, \
+                       x.seg_offsets)
+    if (ragged) {
+        if (hits) hipLaunchKernelGGL((minsnap_sample_kernel<true, false, 8, true>), dim3(B), dim3(SB), lds, ctx->stream, coeffs,
+                                     seg_rows, row_offsets, B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap,
+                                     x.capacity_rows, ctx->d_flags, x.first_yaw, x.seg_offsets);
+        else hipLaunchKernelGGL((minsnap_sample_kernel<false, false, 8, true>), dim3(B), dim3(SB), lds, ctx->stream, coeffs,
+                                seg_rows, row_offsets, B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap,
+                                x.capacity_rows, ctx->d_flags, x.first_yaw, x.seg_offsets);
+    }
+    else if (hits) { if (derivs) UAVAC_SAMPLE(true, true, 8); else UAVAC_SAMPLE(true, false, 8); }
     else if (derivs) UAVAC_SAMPLE(false, true, 8);
     else if (yg == 1) UAVAC_SAMPLE(false, false, 1);
     else if (yg == 4) UAVAC_SAMPLE(false, false, 4);

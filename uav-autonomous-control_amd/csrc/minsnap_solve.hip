@@ -74,18 +74,35 @@ __device__ __forceinline__ int64_t block_inclusive_scan_256(int64_t v, int64_t *
     return v + base;
 }
 
-__global__ void __launch_bounds__(256) row_counts_kernel(const double *__restrict__ wp, int B, int m, double velocity,
+// RAGGED: mission b has m_b = seg_offsets[b + 1] - seg_offsets[b] segments (1 .. m, m = the batch's maximum) and m_b + 1
+// waypoints; waypoints, times and row counts of the batch lie back to back (mission b's first waypoint is waypoint
+// seg_offsets[b] + b, its first segment is segment seg_offsets[b]).  A count outside 1 .. m raises flag 0 and is clamped.
+template <bool RAGGED>
+__global__ void __launch_bounds__(256) row_counts_kernel(const double *__restrict__ wp, int B, int m_uniform, double velocity,
                                                          double dt, double *__restrict__ times,
                                                          int32_t *__restrict__ seg_rows, int32_t *__restrict__ totals,
-                                                         int64_t *__restrict__ tile_sum, int32_t *__restrict__ flags) {
+                                                         int64_t *__restrict__ tile_sum, int32_t *__restrict__ flags,
+                                                         const int64_t *__restrict__ seg_offsets) {
 #pragma clang fp contract(off)
     __shared__ int64_t wsum[4];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = 0;
     if (b < B) {
-        const double *w = wp + (size_t)b * (m + 1) * 3;
+        int m = m_uniform;
+        size_t seg0 = (size_t)b * m_uniform;
+        const double *w = wp + (size_t)b * (m_uniform + 1) * 3;
+        bool bad = false;
+        if (RAGGED) {
+            seg0 = (size_t)seg_offsets[b];
+            const int64_t mb = seg_offsets[b + 1] - seg_offsets[b];
+            bad = mb < 1 || mb > m_uniform;
+            m = (int)(mb < 1 ? 1 : (mb > m_uniform ? m_uniform : mb));
+            w = wp + (seg0 + (size_t)b) * 3;
+        }
+        times += seg0;
+        seg_rows += seg0;
         double x0 = w[0], y0 = w[1], z0 = w[2];
-        bool bad = !(isfinite(x0) && isfinite(y0) && isfinite(z0));
+        bad = bad || !(isfinite(x0) && isfinite(y0) && isfinite(z0));
         for (int s = 0; s < m; ++s) {
             double x1 = w[3 * s + 3], y1 = w[3 * s + 4], z1 = w[3 * s + 5];
             double dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
@@ -94,8 +111,8 @@ __global__ void __launch_bounds__(256) row_counts_kernel(const double *__restric
             bad = bad || !isfinite(T);
             double q = ceil(T / dt);
             int rows = (isfinite(q) && q > 0.0 && q < 2.0e9) ? (int)q : 0;
-            times[(size_t)b * m + s] = T;
-            seg_rows[(size_t)b * m + s] = rows;
+            times[s] = T;
+            seg_rows[s] = rows;
             total += rows;
             x0 = x1; y0 = y1; z0 = z1;
         }
@@ -321,7 +338,7 @@ __global__ void __launch_bounds__(64) minsnap_solve_kernel(const double *__restr
 }  // namespace
 
 int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
-                            double *times, int32_t *seg_rows, int64_t *row_offsets) {
+                            double *times, int32_t *seg_rows, int64_t *row_offsets, const int64_t *seg_offsets) {
     const int n_tiles = (B + 255) / 256;
     if ((size_t)B > ctx->totals_cap) {
         if (ctx->d_totals) UAVAC_HIP(ctx, hipFree(ctx->d_totals));
@@ -334,8 +351,12 @@ int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, doub
     }
     int64_t *tiles = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ctx->d_totals) +
                                                  (((size_t)ctx->totals_cap * 4 + 7) & ~(size_t)7));
-    hipLaunchKernelGGL(row_counts_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, wp, B, m, velocity, dt,
-                       times, seg_rows, ctx->d_totals, tiles, ctx->d_flags);
+    if (seg_offsets)
+        hipLaunchKernelGGL(row_counts_kernel<true>, dim3(n_tiles), dim3(256), 0, ctx->stream, wp, B, m, velocity, dt,
+                           times, seg_rows, ctx->d_totals, tiles, ctx->d_flags, seg_offsets);
+    else
+        hipLaunchKernelGGL(row_counts_kernel<false>, dim3(n_tiles), dim3(256), 0, ctx->stream, wp, B, m, velocity, dt,
+                           times, seg_rows, ctx->d_totals, tiles, ctx->d_flags, seg_offsets);
     hipLaunchKernelGGL(row_offsets_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles,
                        row_offsets);
     UAVAC_HIP(ctx, hipGetLastError());

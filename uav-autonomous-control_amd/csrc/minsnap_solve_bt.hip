@@ -173,20 +173,42 @@ constexpr int TB = 64;          // lanes (missions) per workgroup = one wave
 // inputs loaded where they were used, the parked block read in the compiler's order, four at a time between the FMAs --
 // the kernel took 160 us at B = 65 536, m = 12 for ~30 us of arithmetic.)  No workgroup barrier anywhere: one wave,
 // whose LDS operations execute in order (`lds_wave_fence`; `__syncthreads` would wait for the global stores too).
+// RAGGED: mission b has m_b = seg_offsets[b + 1] - seg_offsets[b] segments (clamped to 1 .. m_uniform = the batch's maximum);
+// waypoints, times and coefficients of the batch lie back to back.  Lanes then run different numbers of knots; the backward
+// sweep counts segments from each mission's own end (lane l handles segment m_l - 1 - i in step i), so that the 64 x 24
+// transpose still moves one segment of every mission that has one left.
+template <bool RAGGED>
 __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__restrict__ wp,
-                                                             const double *__restrict__ times, int B, int m,
+                                                             const double *__restrict__ times, int B, int m_uniform,
                                                              double *__restrict__ ws, double *__restrict__ coeffs,
                                                              int32_t *__restrict__ status,
-                                                             int32_t *__restrict__ flags) {
+                                                             int32_t *__restrict__ flags,
+                                                             const int64_t *__restrict__ seg_offsets) {
     __shared__ double stage[TB * 25];                 // one segment's 24 coefficients per mission (+1 pad)
+    __shared__ int64_t seg0_of[RAGGED ? TB : 1];      // ragged: first segment and segment count of every mission of the wave
+    __shared__ int m_of[RAGGED ? TB : 1];
     const int lane = threadIdx.x;
     const int b0 = blockIdx.x * TB;
     const int b = b0 + lane;
     const bool live = b < B;
     const int bb = live ? b : B - 1;
     const size_t sB = (size_t)B;
-    const double *w = wp + (size_t)bb * (m + 1) * 3;
-    const double *tm = times + (size_t)bb * m;
+    int m = m_uniform;
+    const double *w = wp + (size_t)bb * (m_uniform + 1) * 3;
+    const double *tm = times + (size_t)bb * m_uniform;
+    int m_top = m_uniform;                             // steps of the backward sweep: the longest mission of the wave
+    if (RAGGED) {
+        const int64_t s0 = seg_offsets[bb], mb = seg_offsets[bb + 1] - s0;
+        m = (int)(mb < 1 ? 1 : (mb > m_uniform ? m_uniform : mb));
+        w = wp + ((size_t)s0 + (size_t)bb) * 3;
+        tm = times + (size_t)s0;
+        seg0_of[lane] = s0;
+        m_of[lane] = m;
+        m_top = m;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m_top = max(m_top, __shfl_xor(m_top, d));
+        lds_wave_fence();
+    }
     const int nk = m - 1;
     bool ok = true;
 
@@ -265,12 +287,14 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
 #pragma unroll
         for (int a = 0; a < 3; ++a) xn[i][a] = 0.0;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    // 64 missions x 24 doubles of one segment leave the stage as 192-byte runs: mission q's run is at
-    // coeffs[(b0 + q) * 24 m + 24 s]
-    auto flush = [&](int s) {
+    // 64 missions x 24 doubles of one step leave the stage as 192-byte runs: mission q's segment sq = m_q - 1 - step, at
+    // coeffs[(first segment of q + sq) * 24]
+    auto flush = [&](int step) {
         for (int e = lane; e < TB * 24; e += TB) {
             const int q = e / 24, j = e - q * 24;
-            if (b0 + q < B) coeffs[(size_t)(b0 + q) * 24 * m + 24 * s + j] = stage[q * 25 + j];
+            const int sq = (RAGGED ? m_of[q] : m_uniform) - 1 - step;
+            const size_t first = RAGGED ? (size_t)seg0_of[q] : (size_t)(b0 + q) * m_uniform;
+            if (b0 + q < B && sq >= 0) coeffs[(first + (size_t)sq) * 24 + j] = stage[q * 25 + j];
         }
     };
     // on their way while the segment before is computed: [Ut | rt] of knot s - 1, start waypoint and duration of segment s
@@ -286,13 +310,14 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
         nt = tm[m - 1];
     }
     double p1[3] = {w[3 * m], w[3 * m + 1], w[3 * m + 2]};
-    for (int s = m - 1; s >= 0; --s) {
+    for (int step = 0; step < m_top; ++step) {
+        const int s = m - 1 - step;                     // this lane's segment; < 0: its mission is finished
         double cur[28];
 #pragma unroll
         for (int i = 0; i < 28; ++i) cur[i] = nxt[i];   // (the first use waits for the loads -- and for stores issued a segment ago)
         const double T = nt;
         const double p0[3] = {nw[0], nw[1], nw[2]};
-        if (s + 1 <= m - 1) flush(s + 1);               // reads the stage before this segment overwrites it (LDS is in order)
+        if (step > 0) flush(step - 1);                  // reads the stage before this step overwrites it (LDS is in order)
         if (s >= 2) {
             const double *o = ws + ((size_t)(s - 2) * 28) * sB + bb;
 #pragma unroll
@@ -303,53 +328,55 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
             for (int a = 0; a < 3; ++a) nw[a] = w[3 * (s - 1) + a];
             nt = tm[s - 1];
         }
-        double xs[4][3];                                // unknowns of knot s (zero at the start)
-        if (s >= 1) {
+        if (!RAGGED || s >= 0) {
+            double xs[4][3];                            // unknowns of knot s (zero at the start)
+            if (s >= 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    double v = cur[16 + i * 3 + a];
-                    if (s <= nk - 1) {                  // knot s has a successor among the unknowns
+                    for (int a = 0; a < 3; ++a) {
+                        double v = cur[16 + i * 3 + a];
+                        if (s <= nk - 1) {              // knot s has a successor among the unknowns
 #pragma unroll
-                        for (int l = 0; l < 4; ++l) v = fma(-cur[i * 4 + l], xn[l][a], v);
+                            for (int l = 0; l < 4; ++l) v = fma(-cur[i * 4 + l], xn[l][a], v);
+                        }
+                        xs[i][a] = v;
                     }
-                    xs[i][a] = v;
-                }
-        } else {
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) xs[i][a] = 0.0;
+            }
+            double ip[8];
+            const double r = 1.0 / T;
+            ip[0] = 1.0;
+#pragma unroll
+            for (int e = 1; e < 8; ++e) ip[e] = ip[e - 1] * r;
+            const double x0[3][3] = {{xs[0][0], xs[0][1], xs[0][2]}, {xs[1][0], xs[1][1], xs[1][2]}, {xs[2][0], xs[2][1], xs[2][2]}};
+            const double x1[3][3] = {{xn[0][0], xn[0][1], xn[0][2]}, {xn[1][0], xn[1][1], xn[1][2]}, {xn[2][0], xn[2][1], xn[2][2]}};
+            double c[8][3];
+            segment_coeffs(ip, T, p0, p1, x0, x1, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) stage[lane * 25 + i * 3 + a] = ok ? c[i][a] : qnan;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) xs[i][a] = 0.0;
+                for (int a = 0; a < 3; ++a) xn[i][a] = xs[i][a];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) p1[a] = p0[a];
         }
-        double ip[8];
-        const double r = 1.0 / T;
-        ip[0] = 1.0;
-#pragma unroll
-        for (int e = 1; e < 8; ++e) ip[e] = ip[e - 1] * r;
-        const double x0[3][3] = {{xs[0][0], xs[0][1], xs[0][2]}, {xs[1][0], xs[1][1], xs[1][2]}, {xs[2][0], xs[2][1], xs[2][2]}};
-        const double x1[3][3] = {{xn[0][0], xn[0][1], xn[0][2]}, {xn[1][0], xn[1][1], xn[1][2]}, {xn[2][0], xn[2][1], xn[2][2]}};
-        double c[8][3];
-        segment_coeffs(ip, T, p0, p1, x0, x1, c);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) stage[lane * 25 + i * 3 + a] = ok ? c[i][a] : qnan;
         lds_wave_fence();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) xn[i][a] = xs[i][a];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) p1[a] = p0[a];
     }
-    flush(0);
+    flush(m_top - 1);
 }
 
 }  // namespace
 
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
-                          int32_t *status) {
+                          int32_t *status, const int64_t *seg_offsets) {
     const size_t need = (size_t)(m > 1 ? m - 1 : 1) * 28 * (size_t)B;
     if (need > ctx->ws_cap) {
         if (ctx->d_ws) UAVAC_HIP(ctx, hipFree(ctx->d_ws));
@@ -358,8 +385,12 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
         UAVAC_HIP(ctx, hipMalloc(&ctx->d_ws, sizeof(double) * need));
         ctx->ws_cap = need;
     }
-    hipLaunchKernelGGL(minsnap_solve_bt_kernel, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
-                       ctx->d_ws, coeffs, status, ctx->d_flags);
+    if (seg_offsets)
+        hipLaunchKernelGGL(minsnap_solve_bt_kernel<true>, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
+                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets);
+    else
+        hipLaunchKernelGGL(minsnap_solve_bt_kernel<false>, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
+                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

@@ -396,6 +396,45 @@ int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const 
     return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
 }
 
+// ------------------------------------------------------------------------------- planning, device, ragged batches
+int uavac_minsnap_row_counts_ragged_dev(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, int max_m,
+                                        double velocity, double dt, double *times, int32_t *seg_rows, int64_t *row_offsets) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_plan_args(ctx, wp, B, max_m)) return rc;
+    if (!seg_offsets || !times || !seg_rows || !row_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (!std::isfinite(velocity) || !std::isfinite(dt)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite velocity or dt");
+    if (!(velocity > 0.0) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity and dt must be > 0");
+    return uavac_launch_row_counts(ctx, wp, B, max_m, velocity, dt, times, seg_rows, row_offsets, seg_offsets);
+}
+
+int uavac_minsnap_solve_ragged_dev(uavac_ctx *ctx, const double *wp, const double *times, const int64_t *seg_offsets, int B,
+                                   int max_m, double *coeffs, int32_t *status) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_plan_args(ctx, wp, B, max_m)) return rc;
+    if (!seg_offsets || !times || !coeffs) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    return uavac_launch_solve_bt(ctx, wp, times, B, max_m, coeffs, status, seg_offsets);
+}
+
+int uavac_minsnap_sample_ragged_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *seg_offsets,
+                                    const int64_t *row_offsets, int B, int max_m, int64_t total_segments, double dt,
+                                    double *traj, int64_t traj_capacity_rows, const double *aabb, int32_t *hit,
+                                    double *first_yaw) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_sample_args(ctx, coeffs, seg_rows, row_offsets, B, max_m, dt, traj)) return rc;
+    if (!seg_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "null seg_offsets");
+    if (total_segments < B || total_segments > (int64_t)B * max_m)
+        return uavac_fail(ctx, UAVAC_EINVAL, "total_segments must lie in [B, B * max_m]");
+    if ((aabb == nullptr) != (hit == nullptr)) return uavac_fail(ctx, UAVAC_EINVAL, "aabb and hit go together");
+    SampleExtras x;
+    x.aabb = aabb;
+    x.hit = hit;
+    x.first_yaw = first_yaw;
+    x.capacity_rows = traj_capacity_rows;
+    x.seg_offsets = seg_offsets;
+    x.total_segments = total_segments;
+    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, max_m, dt, traj, x);
+}
+
 int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt, double *times,
                            int32_t *seg_rows, int64_t *row_offsets, double *coeffs, int32_t *status, double *traj,
                            int64_t traj_capacity_rows, double *yaw, double *first_yaw) {

@@ -125,10 +125,12 @@ VehK uavac_make_vehk(const uavac_vehicle &V);
 int uavac_check_vehicle(uavac_ctx *ctx, const uavac_vehicle *V);
 
 // launchers (one per .hip file)
+// seg_offsets (device, [B+1]) != NULL: ragged batch -- mission b has seg_offsets[b+1] - seg_offsets[b] segments (1 .. m,
+// m = the batch's maximum); waypoints, times, row counts, coefficients and hit flags lie back to back
 int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
-                            double *times, int32_t *seg_rows, int64_t *row_offsets);
+                            double *times, int32_t *seg_rows, int64_t *row_offsets, const int64_t *seg_offsets = nullptr);
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
-                          int32_t *status);
+                          int32_t *status, const int64_t *seg_offsets = nullptr);
 int uavac_launch_solve(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                        int32_t *status);
 // Optional outputs / inputs of the sampler (minsnap_sample.hip)
@@ -140,6 +142,8 @@ struct SampleExtras {
     double *jerk = nullptr;          // [rows][3]
     double *snap = nullptr;          // [rows][3]
     int64_t capacity_rows = -1;      // rows the trajectory buffer holds; < 0: not checked
+    const int64_t *seg_offsets = nullptr;   // [B+1] ragged batch (see uavac_launch_row_counts); m is then the maximum
+    int64_t total_segments = -1;            // ... and its number of segments (sizes the hit flags)
 };
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
                         int B, int m, double dt, double *traj, const SampleExtras &x);

@@ -77,6 +77,36 @@ class RaggedPlan:
 
 
 @dataclass
+class RaggedBatch:
+    """One ragged planning call (`Engine.plan_ragged`): B missions with m_b segments each, everything per-segment back to
+    back in mission order (include/uavac.h, "Ragged batches")."""
+    B: int
+    max_m: int
+    velocity: float
+    dt: float
+    seg_offsets: "object"            # (B+1,) i64, device
+    seg_offsets_host: np.ndarray     # the same on the host
+    waypoints: "object"              # (S + B, 3) f64
+    times: "object"                  # (S,) f64
+    seg_rows: "object"               # (S,) i32
+    row_offsets: "object"            # (B+1,) i64
+    coeffs: "object"                 # (S, 8, 3) f64
+    status: "object"                 # (B,) i32, 0 = ok
+    traj: "object"                   # (N, 11) f64
+    total_rows: int
+    first_yaw: "object"              # (B,) f64
+    hit: "object" = None             # (S,) i32 when a cuboid was given
+
+    def mission(self, b: int) -> np.ndarray:
+        ro = self.row_offsets[b:b + 2].cpu().numpy()
+        return self.traj[int(ro[0]):int(ro[1])].cpu().numpy().copy()
+
+    def mission_coeffs(self, b: int) -> np.ndarray:
+        s0, s1 = int(self.seg_offsets_host[b]), int(self.seg_offsets_host[b + 1])
+        return self.coeffs[s0:s1].reshape(-1, 3).cpu().numpy().copy()
+
+
+@dataclass
 class RRTDeviceBatch:
     """Device-resident results of `Engine.rrt_star` (torch tensors; layouts of include/uavac.h).
     counts[:, k]: 0 n_nodes, 1 iterations begun, 2 status, 3 entries when best_tree was stored, 4 best_path rows,
@@ -216,8 +246,9 @@ class Engine:
         Per mission the reference's semantics are kept: obstacles are visited in order; for each one the mission is
         planned, every spline with a sample inside the cuboid gets a midpoint inserted before its end waypoint,
         and it is re-planned until clean; earlier obstacles are not re-checked.  Here all missions advance
-        together: each round plans every still-active mission (grouped by segment count) and the sampler itself
-        reports the hit splines (`uavac_minsnap_sample_hits_dev`); only the midpoint insertion is host work.
+        together: each round plans every still-active mission in ONE ragged batch (`plan_ragged`: their segment counts
+        differ as soon as one has received a midpoint) and the sampler itself reports the hit splines; only the midpoint
+        insertion is host work.
         `waypoints`: (B, m+1, 3) array or a list of (m_b+1, 3) arrays.  The loop is bounded (the reference's is
         not: it cannot end when a waypoint lies inside a cuboid, or when a leg crosses one squarely).  A mission
         that exhausts `max_iterations` or UAVAC_MAX_SEGMENTS raises RuntimeError when `strict`; otherwise it is
@@ -236,30 +267,34 @@ class Engine:
         failed = set()
 
         def run_round(ids, cub):
-            groups = {}
+            """One planning call for every mission of `ids` (their segment counts differ: a ragged batch)."""
+            members = []
             for b in ids:
-                groups.setdefault(wps[b].shape[0] - 1, []).append(b)
-            again = []
-            for m, members in sorted(groups.items()):
-                if m > nat.MAX_SEGMENTS:
+                if wps[b].shape[0] - 1 > nat.MAX_SEGMENTS:
                     if strict:
                         raise RuntimeError(f"obstacle correction needs more than {nat.MAX_SEGMENTS} splines")
-                    failed.update(members)                            # keeps the plan of the previous round
-                    continue
-                plan, hit = self._plan_group(np.stack([wps[b] for b in members]), velocity, dt, cub)
-                for j, b in enumerate(members):
-                    source[b] = (plan, j)
-                if hit is not None:
-                    hit = hit.cpu().numpy().astype(bool)
-                    for j in np.flatnonzero(hit.any(axis=1)):
-                        b = members[j]
-                        idx = np.flatnonzero(hit[j]) + 1              # spline s -> insert before waypoint s+1
-                        if m + len(idx) > nat.MAX_SEGMENTS and not strict:
-                            failed.add(b)                             # would outgrow the kernels: stop here
-                            continue
-                        mids = (wps[b][idx - 1] + wps[b][idx]) / 2
-                        wps[b] = np.insert(wps[b], idx, mids, axis=0)
-                        again.append(b)
+                    failed.add(b)                                     # keeps the plan of the previous round
+                else:
+                    members.append(b)
+            if not members:
+                return []
+            batch = self.plan_ragged([wps[b] for b in members], velocity, dt, cuboid=cub)
+            for j, b in enumerate(members):
+                source[b] = (batch, j)
+            again = []
+            if batch.hit is not None:
+                hit = batch.hit.cpu().numpy().astype(bool)
+                so = batch.seg_offsets_host
+                hit_missions = np.flatnonzero(np.add.reduceat(hit, so[:-1]) > 0) if len(hit) else []
+                for j in hit_missions:
+                    b = members[j]
+                    idx = np.flatnonzero(hit[so[j]:so[j + 1]]) + 1    # spline s -> insert before waypoint s+1
+                    if wps[b].shape[0] - 1 + len(idx) > nat.MAX_SEGMENTS and not strict:
+                        failed.add(b)                                 # would outgrow the kernels: stop here
+                        continue
+                    mids = (wps[b][idx - 1] + wps[b][idx]) / 2
+                    wps[b] = np.insert(wps[b], idx, mids, axis=0)
+                    again.append(b)
             return again
 
         if len(cuboids) == 0:
@@ -309,32 +344,49 @@ class Engine:
         converged[sorted(failed)] = False
         return RaggedPlan(B, float(velocity), float(dt), wps, offsets, traj, total, starts, converged)
 
-    def _plan_group(self, wp_host, velocity, dt, cuboid):
-        """Plan one group of equal-m missions; with a cuboid also return the (B, m) hit flags."""
+    def plan_ragged(self, waypoints, velocity: float = 1.0, dt: float = 0.01, cuboid=None, strict: bool = True) -> RaggedBatch:
+        """`MinimumSnap(path_b, None, velocity, dt).get_trajectory()` for B paths of DIFFERENT lengths in one batch
+        (minimum_snap.py:13-57 takes any path; `Engine.plan` wants equal lengths).  `waypoints`: B arrays (m_b + 1, 3),
+        1 <= m_b <= UAVAC_MAX_SEGMENTS.  Mission b's rows and coefficients equal those of `plan` on it alone, bit for
+        bit.  `cuboid` (6,): also return per-spline hit flags (the collision scan of minimum_snap.py:81-87)."""
         torch = self._torch
-        if cuboid is None:
-            return self.plan(wp_host, velocity, dt), None
-        wp = self._dev(wp_host, torch.float64)
-        B, m = int(wp.shape[0]), int(wp.shape[1]) - 1
+        wps = [np.ascontiguousarray(w, dtype=np.float64) for w in waypoints]
+        B = len(wps)
+        if B == 0 or any(w.ndim != 2 or w.shape[1] != 3 or w.shape[0] < 2 for w in wps):
+            raise ValueError("waypoints must be B arrays of shape (m_b + 1, 3)")
+        counts = np.array([w.shape[0] - 1 for w in wps], dtype=np.int64)
+        max_m = int(counts.max())
+        if max_m > nat.MAX_SEGMENTS:
+            raise ValueError(f"a mission has {max_m} segments; at most {nat.MAX_SEGMENTS}")
+        so_host = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(counts, out=so_host[1:])
+        S = int(so_host[-1])
         kw = dict(device=self.device)
-        times = torch.empty((B, m), dtype=torch.float64, **kw)
-        seg_rows = torch.empty((B, m), dtype=torch.int32, **kw)
+        wp = self._dev(np.concatenate(wps, axis=0), torch.float64)
+        so = self._dev(so_host, torch.int64)
+        times = torch.empty((S,), dtype=torch.float64, **kw)
+        seg_rows = torch.empty((S,), dtype=torch.int32, **kw)
         row_offsets = torch.empty((B + 1,), dtype=torch.int64, **kw)
-        coeffs = torch.empty((B, 8 * m, 3), dtype=torch.float64, **kw)
+        coeffs = torch.empty((S, 8, 3), dtype=torch.float64, **kw)
         status = torch.zeros((B,), dtype=torch.int32, **kw)
-        hit = torch.empty((B, m), dtype=torch.int32, **kw)
-        aabb = self._dev(np.asarray(cuboid, dtype=np.float64).reshape(6), torch.float64)
+        first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
+        hit = aabb = None
+        if cuboid is not None:
+            hit = torch.empty((S,), dtype=torch.int32, **kw)
+            aabb = self._dev(np.asarray(cuboid, dtype=np.float64).reshape(6), torch.float64)
         self._bind_stream()
-        self.ctx.call("uavac_minsnap_row_counts_dev", _ptr(wp), B, m, float(velocity), float(dt), _ptr(times),
-                      _ptr(seg_rows), _ptr(row_offsets))
-        self.ctx.call("uavac_minsnap_solve_dev", _ptr(wp), _ptr(times), B, m, _ptr(coeffs), _ptr(status))
+        self.ctx.call("uavac_minsnap_row_counts_ragged_dev", _ptr(wp), _ptr(so), B, max_m, float(velocity), float(dt),
+                      _ptr(times), _ptr(seg_rows), _ptr(row_offsets))
+        self.ctx.call("uavac_minsnap_solve_ragged_dev", _ptr(wp), _ptr(times), _ptr(so), B, max_m, _ptr(coeffs), _ptr(status))
         total = int(row_offsets[-1].item())
         traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
-        self.ctx.call("uavac_minsnap_sample_hits_dev", _ptr(coeffs), _ptr(times), _ptr(seg_rows), _ptr(row_offsets),
-                      B, m, float(dt), _ptr(traj), _ptr(aabb), _ptr(hit))
-        plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total)
-        self.check(plan)
-        return plan, hit
+        self.ctx.call("uavac_minsnap_sample_ragged_dev", _ptr(coeffs), _ptr(seg_rows), _ptr(so), _ptr(row_offsets), B, max_m,
+                      S, float(dt), _ptr(traj), total, _ptr(aabb), _ptr(hit), _ptr(first_yaw))
+        batch = RaggedBatch(B, max_m, float(velocity), float(dt), so, so_host, wp, times, seg_rows, row_offsets, coeffs, status,
+                            traj, total, first_yaw, hit)
+        if strict:
+            self.check(batch)
+        return batch
 
     def solve(self, plan: Plan):
         """Re-run times/row counts + coefficient solve into plan's buffers (no allocation, no sync)."""
