@@ -533,3 +533,21 @@ def test_ragged_entry_points_reject_bad_arguments(eng, nat):
     eng.ctx.call("uavac_minsnap_sample_ragged_dev", P(rb2.coeffs), P(rb2.seg_rows), P(rb2.seg_offsets), P(rb2.row_offsets), 1, 3,
                  3, 0.01, P(small), 10, P(None), P(None), P(None))
     assert eng.take_flags()[2] == 1 and float(small.abs().sum()) == 0.0
+
+
+def test_fleet_flies_a_ragged_batch_like_uniform_plans(eng):
+    """A RaggedBatch feeds the rollout through its rows (it has no common segment count, so the plan-fed kernel is not
+    offered): every vehicle's log equals the one it gets in a uniform batch of its own length."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    a, b = mo.synthetic_missions(40, 3), mo.synthetic_missions(30, 6)
+    missions = [a[i // 2] if i % 2 == 0 else b[i // 2] for i in range(60)]          # interleaved: 30 of each
+    rb = eng.plan_ragged(missions, 3.0, 0.01)
+    fl = eng.fleet(rb)
+    assert not fl.from_plan
+    with pytest.raises(ValueError):
+        eng.fleet(rb, from_plan=True)
+    log, _ = fl.rollout(1200, state_log=True)
+    la, _ = eng.fleet(eng.plan(a[:30], 3.0, 0.01), from_plan=False).rollout(1200, state_log=True)
+    lb, _ = eng.fleet(eng.plan(b[:30], 3.0, 0.01), from_plan=False).rollout(1200, state_log=True)
+    assert torch.equal(log[:, :, 0::2], la) and torch.equal(log[:, :, 1::2], lb)

@@ -101,6 +101,12 @@ class RaggedBatch:
         ro = self.row_offsets[b:b + 2].cpu().numpy()
         return self.traj[int(ro[0]):int(ro[1])].cpu().numpy().copy()
 
+    @property
+    def start_positions(self):
+        """(B, 3): first waypoint of every mission (what `Fleet` starts its vehicles from)."""
+        first = self.seg_offsets[:-1] + self.seg_offsets.new_tensor(range(self.B))
+        return self.waypoints[first]
+
     def mission_coeffs(self, b: int) -> np.ndarray:
         s0, s1 = int(self.seg_offsets_host[b]), int(self.seg_offsets_host[b + 1])
         return self.coeffs[s0:s1].reshape(-1, 3).cpu().numpy().copy()
@@ -515,7 +521,8 @@ class Fleet:
         # ticks on an MI355X, plan-fed / row-fed: B = 32 768 1.05 / 0.95 ms, 49 152 1.08 / 1.11, 65 536 1.28 / 1.44,
         # 131 072 2.58 / 3.01 (tools/plan_vs_rows.py); below ~40 000 UAVs the chip is not full and the extra
         # arithmetic of evaluating rows costs more than the reads it saves.
-        can = hasattr(plan, "coeffs") and (getattr(plan, "first_yaw", None) is not None or getattr(plan, "yaw", None) is not None)
+        can = (hasattr(plan, "coeffs") and hasattr(plan, "m") and      # one segment count for the whole batch: a RaggedBatch has none
+               (getattr(plan, "first_yaw", None) is not None or getattr(plan, "yaw", None) is not None))
         self.from_plan = (can and plan.B >= self.PLAN_FED_MIN_BATCH) if from_plan is None else bool(from_plan)
         if self.from_plan and not can:
             raise ValueError("this plan has no coefficients / first headings / yaw column to fly from")
