@@ -43,6 +43,7 @@ B_PER_GPU = 65536
 SEGMENTS = 12
 TICKS = 10000
 CHUNK = 1000
+PLACEMENT_TRIALS = 6           # candidate row buffers Engine.plan times the sampler on before keeping one (untimed set-up)
 VELOCITY, DT, F = 3.0, 0.01, 10
 FP64_WAVE_INSTR_PEAK = 39.3e12 / 64  # vector fp64 peak of MI355X_MICROARCH.md: 78.6 TFLOP/s = 39.3 T lane-FMA/s = 614 G wave-instr/s
 GATHER_TIMEOUT_S = 240
@@ -165,7 +166,10 @@ def main():
     B, m = args.batch, SEGMENTS
     eng = Engine(dev)
     wps = missions(B * world, m, rank * B, (rank + 1) * B)
-    plan = eng.plan(wps, VELOCITY, DT)                   # allocates; also the first warm-up
+    # The row buffer is chosen among PLACEMENT_TRIALS allocations by timing the sampler on each (Engine.plan, DESIGN K2: whether
+    # the rows stream out at ~6.0 or ~5.1 TB/s is a property of where the buffer lies, for as long as it lives).  Untimed
+    # set-up, reported in the line.
+    plan = eng.plan(wps, VELOCITY, DT, placement_trials=PLACEMENT_TRIALS)      # allocates; also the first warm-up
     fleet = eng.fleet(plan)
     log = torch.empty((CHUNK, 13, B), dtype=torch.float64, device=dev)
     n_chunks = TICKS // CHUNK
@@ -277,7 +281,11 @@ def main():
                         "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
-                                     "algorithmic_bytes": plan.algorithmic_bytes}},
+                                     "algorithmic_bytes": plan.algorithmic_bytes},
+                        "row_buffer_placement": {"trials": PLACEMENT_TRIALS,
+                                                 "sampler_ms_per_candidate": [round(float(t), 4) for t in (plan.placement_ms or [])],
+                                                 "note": "untimed set-up: the row buffer kept is the candidate allocation "
+                                                         "the sampler streams into fastest (DESIGN K2)"}},
             "rollout_only": {"value": B * CHUNK / roll_avg_s, "unit": "UAV control-steps/s per GPU",
                              "note": "SURVEY 8(d)(i): B x K / time of the rollout launches alone (`value` above also "
                                      "carries the planning time of every step)"},

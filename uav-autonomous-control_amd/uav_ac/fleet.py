@@ -45,6 +45,7 @@ class Plan:
     total_rows: int
     yaw: "object" = None     # (N,) f64 or None: the yaw column on its own (== traj[:, 9]); one way to feed the plan-fed rollout
     first_yaw: "object" = None   # (B,) f64: heading of each mission's first row that has one; lets the rollout scan the yaw itself
+    placement_ms: "object" = None    # sampler times of the candidate row buffers when plan(..., placement_trials > 1) chose one
 
     def mission(self, b: int) -> np.ndarray:
         """Rows of mission b as a fresh host array (N_b, 11) -- the reference's `full_trajectory`."""
@@ -164,12 +165,17 @@ class Engine:
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
 
     # -- planning ---------------------------------------------------------------
-    def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True, dense_yaw: bool = False) -> Plan:
+    def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True, dense_yaw: bool = False,
+             placement_trials: int = 1) -> Plan:
         """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124).
         `strict`: raise UavacError(ESINGULAR) when a mission's knot system is singular (a repeated waypoint) instead of
         returning NaN coefficients for it; with strict=False inspect `plan.status`.
         `dense_yaw`: also keep the yaw column on its own (`plan.yaw`, 8 B per row).  Not needed to fly the plan: the
-        plan-fed rollout scans the yaw itself from `plan.first_yaw` (8 B per mission)."""
+        plan-fed rollout scans the yaw itself from `plan.first_yaw` (8 B per mission).
+        `placement_trials` > 1: where the row buffer lies in HBM decides whether the sampler streams into it at ~6.0 or at
+        ~5.1 TB/s -- a property of the allocation that lasts as long as the buffer (tools/buffer_placement_probe.py, DESIGN
+        K2).  So allocate that many candidate buffers, time the sampler on each, keep the fastest and free the others
+        (`plan.placement_ms` holds the times).  For plans that are re-sampled many times (`replan`)."""
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -193,9 +199,35 @@ class Engine:
         first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
         plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw, first_yaw)
         self.sample(plan)
+        if int(placement_trials) > 1 and total > 0:
+            self._place_rows(plan, int(placement_trials))
         if strict:
             self.check(plan)
         return plan
+
+    def _place_rows(self, plan: Plan, trials: int):
+        torch = self._torch
+        # all candidates alive side by side (a freed block would come straight back from the allocator)
+        candidates = [plan.traj] + [torch.empty_like(plan.traj) for _ in range(trials - 1)]
+
+        def timed(buf):
+            plan.traj = buf
+            self.sample(plan)                                    # first touch of fresh pages is not what is compared
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.sample(plan)
+            self.sample(plan)
+            b.record()
+            b.synchronize()
+            return a.elapsed_time(b) / 2
+
+        for _ in range(8):                                       # clocks up before anything is compared
+            self.sample(plan)
+        forth = [timed(c) for c in candidates]
+        back = [timed(c) for c in reversed(candidates)][::-1]    # and once more in the opposite order
+        times = [(f + k) / 2 for f, k in zip(forth, back)]
+        plan.traj = candidates[int(np.argmin(times))]            # (every candidate holds the same rows)
+        plan.placement_ms = times
 
     def replan(self, plan: Plan):
         """The whole chain again into plan's buffers -- times + row counts, offsets, solve, sampler (+ yaw column) --
