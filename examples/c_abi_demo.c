@@ -3,7 +3,8 @@
  * controller + free-body dynamics, print where the vehicle ends up.  No Python, no torch: only include/uavac.h and
  * libuavac.so (host-pointer entry points; the library stages through device memory itself).  Then the same flight
  * tick by tick through the resident session (uavac_pilot_*: what a host-owned `tc.step(); sim.step()` loop uses), from the
- * ground with the build-defined ground plane, the stand-alone yaw scan, and the multi-GPU gather's RCCL calls on this one
+ * ground with the build-defined ground plane, the stand-alone yaw scan, a ragged batch (missions of different lengths in
+ * one call), and the multi-GPU gather's RCCL calls on this one
  * GPU (communicator of world size 1: counts, the root's own block, a self send/receive through the transport).
  *
  *   gcc examples/c_abi_demo.c -Iinclude -Luav-autonomous-control_amd/lib -luavac \
@@ -86,6 +87,23 @@ int main(void) {
     CHECK(uavac_yaw_scan(ctx, vel, offs[1], yaws));
     int yaw_same = 1;
     for (int64_t r = 0; r < offs[1]; ++r) yaw_same &= yaws[r] == traj[UAVAC_TRAJ_COLS * r + 9];
+
+    /* ---- missions of different lengths in one call: the 4-segment leg above and a 2-segment hop, back to back ---- */
+    const double hop[3][3] = {{14, 10, -2.5}, {17, 8, -2.0}, {20, 10, -2.5}};
+    double rwp[8][3];
+    for (int i = 0; i < 5; ++i) for (int a = 0; a < 3; ++a) rwp[i][a] = wp[i][a];
+    for (int i = 0; i < 3; ++i) for (int a = 0; a < 3; ++a) rwp[5 + i][a] = hop[i][a];
+    const int64_t seg_offsets[3] = {0, 4, 6};
+    int64_t roffs[3];
+    CHECK(uavac_minsnap_plan_ragged(ctx, &rwp[0][0], seg_offsets, 2, velocity, dt, NULL, roffs, NULL, NULL, 0));   /* sizes */
+    double *rtraj = malloc(sizeof(double) * UAVAC_TRAJ_COLS * (size_t)roffs[2]);
+    CHECK(uavac_minsnap_plan_ragged(ctx, &rwp[0][0], seg_offsets, 2, velocity, dt, NULL, roffs, NULL, rtraj, roffs[2]));
+    int ragged_same = roffs[1] == offs[1];
+    for (int64_t i = 0; ragged_same && i < offs[1] * UAVAC_TRAJ_COLS; ++i) ragged_same = rtraj[i] == traj[i];
+    printf("ragged batch: %lld + %lld rows; the first mission equals the uniform plan bit for bit: %s\n", (long long)roffs[1],
+           (long long)(roffs[2] - roffs[1]), ragged_same ? "yes" : "no");
+    free(rtraj);
+    if (!ragged_same) return 3;
 
     /* ---- the gather of the multi-GPU path with a communicator of one rank (N GPUs: one process each, same calls) ---- */
     char id[UAVAC_COMM_ID_BYTES];

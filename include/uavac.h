@@ -189,6 +189,13 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
  * A segment count outside 1 .. max_m raises sticky flag 0 (uavac_take_flags) and is clamped.  The sampler takes the
  * capacity of the row buffer like uavac_minsnap_plan_dev (flag 2 and nothing written when it is too small; < 0: not
  * checked), an optional cuboid + hit flags (both or neither) and optional first_yaw [B]. */
+/* The same on HOST buffers, the whole chain in one call (seg_offsets on the host; validated: 1 .. UAVAC_MAX_SEGMENTS
+ * segments each): times [S] and coeffs [S][8][3] optional (NULL), row_offsets [B+1] always; traj NULL (or
+ * traj_capacity_rows < row_offsets[B]: UAVAC_EINVAL after everything else was produced) skips the rows -- call once with
+ * traj = NULL to learn row_offsets[B], allocate, call again. */
+int uavac_minsnap_plan_ragged(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, double velocity,
+                              double dt, double *times, int64_t *row_offsets, double *coeffs, double *traj,
+                              int64_t traj_capacity_rows);
 int uavac_minsnap_row_counts_ragged_dev(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B,
                                         int max_m, double velocity, double dt, double *times,
                                         int32_t *seg_rows, int64_t *row_offsets);

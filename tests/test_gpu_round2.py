@@ -565,3 +565,35 @@ def test_row_buffer_placement_trials_keep_the_rows(eng):
     assert torch.equal(plain.traj, placed.traj) and torch.equal(plain.first_yaw, placed.first_yaw)
     eng.replan(placed)
     assert torch.equal(plain.traj, placed.traj)
+
+
+def test_host_pointer_ragged_plan_equals_the_device_path(eng, nat):
+    """uavac_minsnap_plan_ragged (host buffers, one call): sizing call with traj = NULL, then the full call; equals
+    Engine.plan_ragged on the same missions bit for bit; bad segment tables and a short row buffer are refused."""
+    from oracle import minsnap_oracle as mo
+    missions = [mo.synthetic_missions(1, m)[0] for m in (3, 1, 7, 12, 2)]
+    rb = eng.plan_ragged(missions, 3.0, 0.01)
+    wp = np.ascontiguousarray(np.concatenate(missions))
+    so = np.ascontiguousarray(rb.seg_offsets_host)
+    S, B = int(so[-1]), len(missions)
+    ro = np.zeros(B + 1, np.int64)
+    null = C.c_void_p(0)
+    eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(wp), nat.np_ptr(so), B, 3.0, 0.01, null, nat.np_ptr(ro), null, null, 0)
+    assert np.array_equal(ro, rb.row_offsets.cpu().numpy())
+    times, coeffs, traj = np.empty(S), np.empty((S, 8, 3)), np.empty((int(ro[-1]), nat.TRAJ_COLS))
+    eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(wp), nat.np_ptr(so), B, 3.0, 0.01, nat.np_ptr(times), nat.np_ptr(ro),
+                 nat.np_ptr(coeffs), nat.np_ptr(traj), len(traj))
+    assert np.array_equal(times, rb.times.cpu().numpy()) and np.array_equal(coeffs, rb.coeffs.cpu().numpy())
+    assert np.array_equal(traj, rb.traj.cpu().numpy())
+    with pytest.raises(nat.UavacError) as e:                        # a row buffer one row short
+        eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(wp), nat.np_ptr(so), B, 3.0, 0.01, null, nat.np_ptr(ro), null,
+                     nat.np_ptr(traj), len(traj) - 1)
+    assert e.value.code == nat.EINVAL
+    bad = so.copy(); bad[2] = bad[1]                                # a mission without a segment
+    with pytest.raises(nat.UavacError) as e:
+        eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(wp), nat.np_ptr(bad), B, 3.0, 0.01, null, nat.np_ptr(ro), null, null, 0)
+    assert e.value.code == nat.EINVAL
+    wp2 = wp.copy(); wp2[3, 1] = np.nan
+    with pytest.raises(nat.UavacError) as e:
+        eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(wp2), nat.np_ptr(so), B, 3.0, 0.01, null, nat.np_ptr(ro), null, null, 0)
+    assert e.value.code == nat.ENONFINITE

@@ -555,6 +555,71 @@ int uavac_minsnap_sample(uavac_ctx *ctx, const double *coeffs, const double *tim
     return UAVAC_OK;
 }
 
+// One call for a ragged batch on host buffers: durations, row offsets, coefficients and rows.  `traj` may be NULL (or too small:
+// traj_capacity_rows): then everything but the rows is produced, row_offsets[B] says how many rows a second call needs.
+int uavac_minsnap_plan_ragged(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, double velocity, double dt,
+                              double *times, int64_t *row_offsets, double *coeffs, double *traj, int64_t traj_capacity_rows) {
+    UAVAC_ENTER(ctx);
+    if (B < 1 || !wp || !seg_offsets || !row_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    if (seg_offsets[0] != 0) return uavac_fail(ctx, UAVAC_EINVAL, "seg_offsets must start at 0");
+    int max_m = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t mb = seg_offsets[b + 1] - seg_offsets[b];
+        if (mb < 1 || mb > UAVAC_MAX_SEGMENTS)
+            return uavac_fail(ctx, UAVAC_EINVAL, "every mission needs 1 .. UAVAC_MAX_SEGMENTS segments");
+        if (mb > max_m) max_m = (int)mb;
+    }
+    const size_t S = (size_t)seg_offsets[B], nwp = (S + (size_t)B) * 3, nco = S * 24;
+    if (!finite_all(wp, nwp) || !std::isfinite(velocity) || !std::isfinite(dt))
+        return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite waypoint, velocity or dt");
+    if (!(velocity > 0.0) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity and dt must be > 0");
+    const size_t fixed = uavac_arena_size(nwp * 8) + 2 * uavac_arena_size(((size_t)B + 1) * 8) + uavac_arena_size(S * 8) +
+                         uavac_arena_size(S * 4) + uavac_arena_size(nco * 8);
+    auto stage_inputs = [&](size_t row_bytes, double *&dwp, int64_t *&dso, double *&dtm, int32_t *&dsr, int64_t *&dro,
+                            double *&dco, double *&dtr) -> int {
+        if (int rc = uavac_arena_reserve(ctx, fixed + uavac_arena_size(row_bytes))) return rc;
+        dwp = take<double>(ctx, nwp); dso = take<int64_t>(ctx, (size_t)B + 1); dtm = take<double>(ctx, S);
+        dsr = take<int32_t>(ctx, S); dro = take<int64_t>(ctx, (size_t)B + 1); dco = take<double>(ctx, nco);
+        dtr = row_bytes ? take<double>(ctx, row_bytes / 8) : nullptr;
+        if (int rc = h2d_staged(ctx, dwp, wp, nwp * 8)) return rc;
+        return h2d_staged(ctx, dso, seg_offsets, ((size_t)B + 1) * 8);
+    };
+    double *dwp, *dtm, *dco, *dtr;
+    int64_t *dso, *dro;
+    int32_t *dsr;
+    if (int rc = clear_flags(ctx)) return rc;
+    if (int rc = stage_inputs(0, dwp, dso, dtm, dsr, dro, dco, dtr)) return rc;
+    if (int rc = uavac_launch_row_counts(ctx, dwp, B, max_m, velocity, dt, dtm, dsr, dro, dso)) return rc;
+    if (int rc = d2h_staged(ctx, row_offsets, dro, ((size_t)B + 1) * 8)) return rc;
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t fl[4];
+    if (int rc = read_flags(ctx, fl)) return rc;
+    if (fl[0]) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite segment duration");
+    if (fl[3]) return uavac_fail(ctx, UAVAC_EINVAL, "a mission has more than 2^31-1 rows");
+    const int64_t total = row_offsets[B];
+    const bool rows = traj && traj_capacity_rows >= total && total > 0;
+    if (rows) {             // the arena grows for the rows: stage again (cheap next to the rows) and redo the counts
+        if (int rc = stage_inputs((size_t)total * UAVAC_TRAJ_COLS * 8, dwp, dso, dtm, dsr, dro, dco, dtr)) return rc;
+        if (int rc = uavac_launch_row_counts(ctx, dwp, B, max_m, velocity, dt, dtm, dsr, dro, dso)) return rc;
+    }
+    if (int rc = uavac_launch_solve_bt(ctx, dwp, dtm, B, max_m, dco, nullptr, dso)) return rc;
+    if (rows) {
+        SampleExtras x;
+        x.seg_offsets = dso;
+        x.total_segments = (int64_t)S;
+        x.capacity_rows = total;
+        if (int rc = uavac_launch_sample(ctx, dco, dsr, dro, B, max_m, dt, dtr, x)) return rc;
+        if (int rc = d2h_staged(ctx, traj, dtr, (size_t)total * UAVAC_TRAJ_COLS * 8)) return rc;
+    }
+    if (times) if (int rc = d2h_staged(ctx, times, dtm, S * 8)) return rc;
+    if (coeffs) if (int rc = d2h_staged(ctx, coeffs, dco, nco * 8)) return rc;
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = read_flags(ctx, fl)) return rc;
+    if (fl[1]) return uavac_fail(ctx, UAVAC_ESINGULAR, "singular knot system (repeated waypoint?)");
+    if (traj && !rows && total > 0) return uavac_fail(ctx, UAVAC_EINVAL, "traj_capacity_rows < row_offsets[B]: nothing sampled");
+    return UAVAC_OK;
+}
+
 int uavac_yaw_scan(uavac_ctx *ctx, const double *velocities, int64_t n, double *yaws) {
     UAVAC_ENTER(ctx);
     if (n < 0 || (n > 0 && (!velocities || !yaws))) return uavac_fail(ctx, UAVAC_EINVAL, "bad n or null pointer");
