@@ -43,7 +43,7 @@ B_PER_GPU = 65536
 SEGMENTS = 12
 TICKS = 10000
 CHUNK = 1000
-PLACEMENT_TRIALS = 6           # candidate row buffers Engine.plan times the sampler on before keeping one (untimed set-up)
+PLACEMENT_TRIALS = 16           # candidate row buffers Engine.plan times the sampler on before keeping one (untimed set-up)
 VELOCITY, DT, F = 3.0, 0.01, 10
 FP64_WAVE_INSTR_PEAK = 39.3e12 / 64  # vector fp64 peak of MI355X_MICROARCH.md: 78.6 TFLOP/s = 39.3 T lane-FMA/s = 614 G wave-instr/s
 GATHER_TIMEOUT_S = 240

@@ -555,13 +555,13 @@ def test_fleet_flies_a_ragged_batch_like_uniform_plans(eng):
 
 def test_row_buffer_placement_trials_keep_the_rows(eng):
     """Engine.plan(..., placement_trials=3) times the sampler on three candidate row buffers and keeps one: same rows as a
-    plain plan, three recorded times, the kept buffer is the fastest candidate's."""
+    plain plan, two or three recorded times (it stops at the first clearly faster candidate), the kept buffer is the fastest."""
     import torch
     from oracle import minsnap_oracle as mo
     wps = mo.synthetic_missions(500, 6)
     plain = eng.plan(wps, 3.0, 0.01)
     placed = eng.plan(wps, 3.0, 0.01, placement_trials=3)
-    assert plain.placement_ms is None and len(placed.placement_ms) == 3 and min(placed.placement_ms) > 0
+    assert plain.placement_ms is None and 2 <= len(placed.placement_ms) <= 3 and min(placed.placement_ms) > 0
     assert torch.equal(plain.traj, placed.traj) and torch.equal(plain.first_yaw, placed.first_yaw)
     eng.replan(placed)
     assert torch.equal(plain.traj, placed.traj)

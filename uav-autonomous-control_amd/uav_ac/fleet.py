@@ -174,8 +174,9 @@ class Engine:
         plan-fed rollout scans the yaw itself from `plan.first_yaw` (8 B per mission).
         `placement_trials` > 1: where the row buffer lies in HBM decides whether the sampler streams into it at ~6.0 or at
         ~5.1 TB/s -- a property of the allocation that lasts as long as the buffer (tools/buffer_placement_probe.py, DESIGN
-        K2).  So allocate that many candidate buffers, time the sampler on each, keep the fastest and free the others
-        (`plan.placement_ms` holds the times).  For plans that are re-sampled many times (`replan`)."""
+        K2).  So allocate up to that many candidate buffers one after the other, time the sampler on each, stop at the first
+        one of the fast group (7 % below the slowest seen), keep the fastest and free the others (`plan.placement_ms` holds
+        the times).  For plans that are re-sampled many times (`replan`)."""
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -207,25 +208,29 @@ class Engine:
 
     def _place_rows(self, plan: Plan, trials: int):
         torch = self._torch
-        # all candidates alive side by side (a freed block would come straight back from the allocator)
-        candidates = [plan.traj] + [torch.empty_like(plan.traj) for _ in range(trials - 1)]
 
         def timed(buf):
             plan.traj = buf
             self.sample(plan)                                    # first touch of fresh pages is not what is compared
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            self.sample(plan)
-            self.sample(plan)
+            for _ in range(3):
+                self.sample(plan)
             b.record()
             b.synchronize()
-            return a.elapsed_time(b) / 2
+            return a.elapsed_time(b) / 3
 
         for _ in range(8):                                       # clocks up before anything is compared
             self.sample(plan)
-        forth = [timed(c) for c in candidates]
-        back = [timed(c) for c in reversed(candidates)][::-1]    # and once more in the opposite order
-        times = [(f + k) / 2 for f, k in zip(forth, back)]
+        # all candidates stay alive side by side until the choice is made (a freed block would come straight back from
+        # the allocator); the times fall into two groups ~15 % apart: stop at the first candidate of the fast group
+        candidates, times = [plan.traj], [timed(plan.traj)]
+        while len(candidates) < trials and not (len(times) > 1 and min(times) < 0.93 * max(times)):
+            try:
+                candidates.append(torch.empty_like(candidates[0]))
+            except RuntimeError:                                 # out of memory: choose among what there is
+                break
+            times.append(timed(candidates[-1]))
         plan.traj = candidates[int(np.argmin(times))]            # (every candidate holds the same rows)
         plan.placement_ms = times
 
