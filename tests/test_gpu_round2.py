@@ -597,3 +597,42 @@ def test_host_pointer_ragged_plan_equals_the_device_path(eng, nat):
     with pytest.raises(nat.UavacError) as e:
         eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(wp2), nat.np_ptr(so), B, 3.0, 0.01, null, nat.np_ptr(ro), null, null, 0)
     assert e.value.code == nat.ENONFINITE
+
+
+# ------------------------------------------------------------------------------------- vehicles other than Table V
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_rollout_with_another_vehicle_matches_the_c_oracle(eng, nat, seed):
+    """Every field of the vehicle (mass, inertia, arm, rotor constants, thrust limits, motor time constants, flight limits,
+    all eleven gains, tick lengths) drawn away from Table V: the fused kernel -- which keeps these constants in a mixture of
+    scalar and vector registers and folds several of them into reciprocals and products -- against the scalar C oracle,
+    row-fed and plan-fed, with both logs."""
+    import torch
+    from oracle import c_oracle as cc
+    from oracle import minsnap_oracle as mo
+    rng = np.random.default_rng(seed)
+    V, Vc = nat.Vehicle.default(), cc.Vehicle.default()
+    def both(name, value):
+        setattr(V, name, value); setattr(Vc, name, value)
+    F = int(rng.choice([5, 8, 10]))
+    both("dt", float(rng.choice([0.001, 0.002]))); both("inner_per_outer", F); both("dt_outer", V.dt * F)
+    both("mass", float(rng.uniform(0.35, 0.9)))
+    for i, s in enumerate(rng.uniform(0.7, 1.6, 3)):
+        V.inertia[i] *= s; Vc.inertia[i] = V.inertia[i]
+    for name in ("arm", "kf", "kappa", "tau_rise", "tau_fall", "max_ascent", "max_descent", "max_speed_xy", "max_horiz_accel",
+                 "kp_xy", "kd_xy", "kp_z", "kd_z", "ki_z", "kp_roll", "kp_pitch", "kp_yaw", "kp_p", "kp_q", "kp_r"):
+        both(name, getattr(V, name) * float(rng.uniform(0.8, 1.25)))
+    both("max_tilt", float(rng.uniform(0.5, 0.8)))
+    both("min_thrust", float(rng.uniform(0.05, 0.15))); both("max_thrust", V.mass * 9.81 / 4 * float(rng.uniform(2.5, 4.0)))
+    plan = eng.plan(mo.synthetic_missions(96, 6), 2.0, V.dt_outer)
+    K = 1500
+    for from_plan in (False, True):
+        fleet = eng.fleet(plan, vehicle=V, from_plan=from_plan)
+        slog, clog = fleet.rollout(K, state_log=True, cmd_log=True)
+        assert bool(torch.isfinite(slog).all())
+        for b in (0, 41, 95):
+            traj = plan.mission(b)
+            state, istate = cc.initial_state(traj[0, 0:3], Vc)
+            s_ref, c_ref = cc.rollout(traj, state, istate, K, Vc)
+            assert col_err(slog[:, :, b].cpu().numpy(), s_ref) < 1e-9, (from_plan, b)
+            assert col_err(clog[:, :, b].cpu().numpy(), c_ref) < 1e-9, (from_plan, b)
+            assert int(fleet.trajectory_index[b]) == istate[0]
