@@ -274,6 +274,14 @@ int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const
                                    const double *yaw, const double *first_yaw, int m, double dt,
                                    double *state, int32_t *istate, int B, int K, double *state_log,
                                    double *cmd_log, const double *aabbs, int n_obs);
+
+/* The same for a ragged batch (uavac_minsnap_*_ragged_dev): coeffs [S][8][3] and seg_rows [S] back to back, mission b's
+ * segments at seg_offsets[b] .. seg_offsets[b+1]; the vehicles scan the yaw themselves from first_yaw [B]. */
+int uavac_control_rollout_plan_ragged_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *coeffs,
+                                          const int32_t *seg_rows, const int64_t *seg_offsets,
+                                          const int64_t *row_offsets, const double *first_yaw, int max_m,
+                                          double dt, double *state, int32_t *istate, int B, int K,
+                                          double *state_log, double *cmd_log, const double *aabbs, int n_obs);
 /* One tick (K = 1, no logs): the literal drop-in of tc.step() + simulation.step(). */
 int uavac_control_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
                            const int64_t *row_offsets, double *state, int32_t *istate, int B);

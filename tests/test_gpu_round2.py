@@ -536,8 +536,9 @@ def test_ragged_entry_points_reject_bad_arguments(eng, nat):
 
 
 def test_fleet_flies_a_ragged_batch_like_uniform_plans(eng):
-    """A RaggedBatch feeds the rollout through its rows (it has no common segment count, so the plan-fed kernel is not
-    offered): every vehicle's log equals the one it gets in a uniform batch of its own length."""
+    """A RaggedBatch feeds the rollout through its rows (the default below 40 960 vehicles) or through its coefficients
+    (plan-fed, uavac_control_rollout_plan_ragged_dev): every vehicle's log equals, bit for bit, the one it gets in a uniform
+    batch of its own length; split launches and single ticks included."""
     import torch
     from oracle import minsnap_oracle as mo
     a, b = mo.synthetic_missions(40, 3), mo.synthetic_missions(30, 6)
@@ -545,9 +546,15 @@ def test_fleet_flies_a_ragged_batch_like_uniform_plans(eng):
     rb = eng.plan_ragged(missions, 3.0, 0.01)
     fl = eng.fleet(rb)
     assert not fl.from_plan
-    with pytest.raises(ValueError):
-        eng.fleet(rb, from_plan=True)
     log, _ = fl.rollout(1200, state_log=True)
+    fed = eng.fleet(rb, from_plan=True)
+    flog1, _ = fed.rollout(450, state_log=True)
+    fed.rollout(1)
+    flog2, _ = fed.rollout(749, state_log=True)
+    assert torch.equal(flog1, log[:450]) and torch.equal(flog2, log[451:])
+    assert torch.equal(fed.state[:26], fl.state[:26]) and torch.equal(fed.istate, fl.istate)
+    with pytest.raises(ValueError):
+        eng.fleet(rb, from_plan=True, yaw_from="column").rollout(1)
     la, _ = eng.fleet(eng.plan(a[:30], 3.0, 0.01), from_plan=False).rollout(1200, state_log=True)
     lb, _ = eng.fleet(eng.plan(b[:30], 3.0, 0.01), from_plan=False).rollout(1200, state_log=True)
     assert torch.equal(log[:, :, 0::2], la) and torch.equal(log[:, :, 1::2], lb)

@@ -282,8 +282,17 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     // POLY: segment / row-in-segment of the cursor, the segment's coefficients and the next 16 yaws, in LDS
     double *cf = slab + (size_t)2 * NR * NU + (size_t)(tid >> 6) * poly_tile_doubles(YAWSCAN) + (tid & 63);      // cf[j * 64]
     double *yw = cf + 24 * 64;                                                                          // yw[j * 64]
-    const int32_t *seg_rows = POLY ? P.seg_rows + (size_t)bb * P.m : nullptr;
-    const double *mission_coeffs = POLY ? P.coeffs + (size_t)bb * 24 * P.m : nullptr;
+    // segments of this lane's mission: P.m of them at bb * P.m, or -- ragged batch -- seg_offsets[bb + 1] - seg_offsets[bb]
+    // of them at seg_offsets[bb] (clamped to 1 .. P.m, the batch's maximum)
+    int pm = P.m;
+    size_t seg0 = (size_t)bb * P.m;
+    if (POLY && P.seg_offsets) {
+        seg0 = (size_t)P.seg_offsets[bb];
+        const int64_t n_ = P.seg_offsets[bb + 1] - P.seg_offsets[bb];
+        pm = (int)(n_ < 1 ? 1 : (n_ > P.m ? P.m : n_));
+    }
+    const int32_t *seg_rows = POLY ? P.seg_rows + seg0 : nullptr;
+    const double *mission_coeffs = POLY ? P.coeffs + seg0 * 24 : nullptr;
     const double *yaws = (POLY && !YAWSCAN) ? P.yaw + off : nullptr;
     int seg = 0, rin = 0, srows = 0, ybase = 0;
     auto load_coeffs = [&](int s_) {
@@ -313,7 +322,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 int s_ = 0, r_ = 0, n_ = seg_rows[0];
                 load_coeffs(0);
                 for (int row = 0; row < idx; ++row) {
-                    while (r_ >= n_ && s_ + 1 < P.m) { r_ -= n_; ++s_; n_ = seg_rows[s_]; load_coeffs(s_); }
+                    while (r_ >= n_ && s_ + 1 < pm) { r_ -= n_; ++s_; n_ = seg_rows[s_]; load_coeffs(s_); }
                     double x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_;
                     minsnap_eval_row<64>(cf, (double)r_ * P.dt, x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_);
                     if (uavac_yaw::has_heading(vx_, vy_)) {
@@ -328,7 +337,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         }
         rin = idx;
         srows = seg_rows[0];
-        while (seg + 1 < P.m && rin >= srows) { rin -= srows; ++seg; srows = seg_rows[seg]; }
+        while (seg + 1 < pm && rin >= srows) { rin -= srows; ++seg; srows = seg_rows[seg]; }
         load_coeffs(seg);
         if (!YAWSCAN) {
             ybase = idx;
@@ -393,7 +402,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 if (idx + 1 < nrows) {                    // main.py:61: the cursor stops on the last row
                     ++idx;
                     if (++rin >= srows) {                 // next segment (skipping empty ones, like the sampler's segment_of)
-                        while (rin >= srows && seg + 1 < P.m) { rin -= srows; ++seg; srows = seg_rows[seg]; }
+                        while (rin >= srows && seg + 1 < pm) { rin -= srows; ++seg; srows = seg_rows[seg]; }
                         load_coeffs(seg);
                     }
                     if (!YAWSCAN && idx - ybase == 16) { ybase = idx; load_yaws(ybase); }

@@ -676,6 +676,24 @@ int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const
                                 aabbs, n_obs, &plan);
 }
 
+int uavac_control_rollout_plan_ragged_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *coeffs, const int32_t *seg_rows,
+                                          const int64_t *seg_offsets, const int64_t *row_offsets, const double *first_yaw,
+                                          int max_m, double dt, double *state, int32_t *istate, int B, int K,
+                                          double *state_log, double *cmd_log, const double *aabbs, int n_obs) {
+    UAVAC_ENTER(ctx);
+    if (int rc = uavac_check_vehicle(ctx, V)) return rc;
+    if (int rc = check_plan_args(ctx, coeffs, B, max_m)) return rc;
+    if (K < 0 || !seg_rows || !seg_offsets || !row_offsets || !first_yaw || !state || !istate || n_obs < 0)
+        return uavac_fail(ctx, UAVAC_EINVAL, "bad size or null pointer");
+    if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
+    if (K == 0) return UAVAC_OK;
+    PlanRef plan;
+    plan.coeffs = coeffs; plan.seg_rows = seg_rows; plan.first_yaw = first_yaw; plan.dt = dt; plan.m = max_m;
+    plan.seg_offsets = seg_offsets;
+    return uavac_launch_rollout(ctx, uavac_make_vehk(*V), nullptr, row_offsets, state, istate, B, K, state_log, cmd_log,
+                                aabbs, n_obs, &plan);
+}
+
 int uavac_control_step_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj, const int64_t *row_offsets,
                            double *state, int32_t *istate, int B) {
     return uavac_control_rollout_dev(ctx, V, traj, row_offsets, state, istate, B, 1, nullptr, nullptr, nullptr, 0);

@@ -158,6 +158,7 @@ struct PlanRef {
     const double *first_yaw = nullptr;   // [B] (with yaw == NULL) heading the rows before a mission's first heading take
     double dt = 0.0;
     int m = 0;
+    const int64_t *seg_offsets = nullptr;   // [B+1] ragged batch: coeffs [S][8][3], seg_rows [S] back to back, m = the maximum
 };
 int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                          int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs,

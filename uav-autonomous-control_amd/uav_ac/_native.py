@@ -90,6 +90,8 @@ _SIGNATURES = {
     "uavac_control_rollout_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
     "uavac_control_rollout_plan_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, _P, C.c_int, C.c_double, _P, _P,
                                                   C.c_int, C.c_int, _P, _P, _P, C.c_int]),
+    "uavac_control_rollout_plan_ragged_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, _P, C.c_int, C.c_double, _P, _P,
+                                                         C.c_int, C.c_int, _P, _P, _P, C.c_int]),
     "uavac_control_step_dev": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int]),
     "uavac_state_init": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P, _P]),
     "uavac_control_rollout": (C.c_int, [_P, C.POINTER(Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
@@ -154,7 +156,12 @@ def lib() -> C.CDLL:
             pass
         _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(_lib, name)
+            try:
+                fn = getattr(_lib, name)
+            except AttributeError:
+                if os.environ.get("UAVAC_LIB"):        # an older build loaded for an A/B: it may lack the newest entry points
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
     return _lib

@@ -558,7 +558,8 @@ class Fleet:
         # ticks on an MI355X, plan-fed / row-fed: B = 32 768 1.05 / 0.95 ms, 49 152 1.08 / 1.11, 65 536 1.28 / 1.44,
         # 131 072 2.58 / 3.01 (tools/plan_vs_rows.py); below ~40 000 UAVs the chip is not full and the extra
         # arithmetic of evaluating rows costs more than the reads it saves.
-        can = (hasattr(plan, "coeffs") and hasattr(plan, "m") and      # one segment count for the whole batch: a RaggedBatch has none
+        # a Plan (one segment count for the whole batch) or a RaggedBatch (seg_offsets); a RaggedPlan has rows only
+        can = (hasattr(plan, "coeffs") and (hasattr(plan, "m") or hasattr(plan, "seg_offsets")) and
                (getattr(plan, "first_yaw", None) is not None or getattr(plan, "yaw", None) is not None))
         self.from_plan = (can and plan.B >= self.PLAN_FED_MIN_BATCH) if from_plan is None else bool(from_plan)
         if self.from_plan and not can:
@@ -602,7 +603,13 @@ class Fleet:
             n_obs = int(ab.shape[0])
         e._bind_stream()
         p = self.plan
-        if self.from_plan:
+        if self.from_plan and hasattr(p, "seg_offsets"):
+            if self.yaw_from == "column":
+                raise ValueError("a ragged batch has no dense yaw column: yaw_from='scan'")
+            e.ctx.call("uavac_control_rollout_plan_ragged_dev", C.byref(self.vehicle), _ptr(p.coeffs), _ptr(p.seg_rows),
+                       _ptr(p.seg_offsets), _ptr(p.row_offsets), _ptr(p.first_yaw), p.max_m, float(p.dt), _ptr(self.state),
+                       _ptr(self.istate), self.B, int(K), _ptr(state_log), _ptr(cmd_log), _ptr(ab), n_obs)
+        elif self.from_plan:
             # target rows are evaluated inside the kernel from the plan's coefficients; the yaw is scanned by the kernel
             # (plan.first_yaw) unless only the dense column exists or `yaw_from="column"` was asked for
             first = getattr(p, "first_yaw", None)
