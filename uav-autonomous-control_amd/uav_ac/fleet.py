@@ -105,7 +105,8 @@ class RaggedBatch:
     @property
     def start_positions(self):
         """(B, 3): first waypoint of every mission (what `Fleet` starts its vehicles from)."""
-        first = self.seg_offsets[:-1] + self.seg_offsets.new_tensor(range(self.B))
+        import torch
+        first = self.seg_offsets[:-1] + torch.arange(self.B, dtype=self.seg_offsets.dtype, device=self.seg_offsets.device)
         return self.waypoints[first]
 
     def mission_coeffs(self, b: int) -> np.ndarray:
