@@ -18,7 +18,9 @@ constexpr double kIntegralLimit = 10.0;     // CascadedController.INTEGRAL_ERROR
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
-// A constant that lives in a vector register.  fp64 literals that are not inline constants cannot be encoded in a vector
+// A constant that lives in a vector register.  (Call it ONCE, ahead of the loop that uses the value: the asm ties its input
+// to its output, so executed inside a loop it costs a v_mov_b64 per execution -- the literals of the per-tick path therefore
+// travel in VehK (lit_*) and are laundered in the rollout's prologue, not where they are used.)  fp64 literals that are not inline constants cannot be encoded in a vector
 // instruction: the compiler builds them in a scalar register pair (two s_mov_b32), and in the rollout's tick loop -- whose
 // ~50 vehicle constants already overflow the scalar file, at the price of v_readlane / v_writelane spills inside the loop --
 // it rebuilds them on every tick.  Laundered through an empty (non-volatile, hoistable) asm they are loaded once, ahead of the
@@ -26,6 +28,15 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) { retur
 __device__ __forceinline__ double vk(double x) {
     asm("" : "+v"(x));
     return x;
+}
+
+// fma(a, b, k) with the constant k of vk() as the addend, written as ONE v_fma_f64.  Left to itself the compiler makes a
+// v_fmac_f64 of it (destination = addend) and, the constant having to survive, copies it into the destination first: a
+// v_mov_b64 per Horner step, as expensive on this part as the FMA itself (tools/fp64_operand_probe.hip).
+__device__ __forceinline__ double fmak(double a, double b, double k) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
+    return d;
 }
 
 // Python's float `%` for a positive divisor (controller.py:173,178): fmod, then + b when the remainder is negative.
@@ -61,8 +72,8 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 // sqrt(x) for x >= 0: Goldschmidt step on the rsq seed + one residual correction.  x is floored at the
 // smallest normal so that x == 0 needs no special case (returns 1.5e-154 instead of 0).
-__device__ __forceinline__ double fast_sqrt(double x) {
-    x = fmax(x, vk(2.2250738585072014e-308));
+__device__ __forceinline__ double fast_sqrt(double x, double smallest_normal) {
+    x = fmax(x, smallest_normal);
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
@@ -187,7 +198,7 @@ __device__ __forceinline__ void allocate(const VehK &V, double thrust, double Mx
 __device__ __forceinline__ void motors(const VehK &V, const double f[4], double om[4], double omc[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        omc[i] = fast_sqrt(f[i] * V.inv_kf);
+        omc[i] = fast_sqrt(f[i] * V.inv_kf, V.lit_tiny);
         const double resp = (omc[i] > om[i]) ? V.resp_rise : V.resp_fall;
         om[i] = fma(resp, omc[i] - om[i], om[i]);
     }
@@ -246,10 +257,10 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
     const double w2 = fma(wp, wp, fma(wq, wq, wr * wr));
     const double h2 = 0.25 * V.dt * V.dt * w2;
     double ch, sh_over;                           // cos(h), sin(h)/|w| = (dt/2) sinc(h)
-    if (h2 < vk(1.0e-3)) {
+    if (h2 < V.lit_h2_small) {
         // |h| < 0.0316 (|w| < 63 rad/s at dt = 1 ms): Taylor series through h^8, truncation < 3e-22
-        ch = fma(h2, fma(h2, fma(h2, fma(h2, vk(1.0 / 40320), vk(-1.0 / 720)), vk(1.0 / 24)), -0.5), 1.0);
-        const double sinc = fma(h2, fma(h2, fma(h2, fma(h2, vk(1.0 / 362880), vk(-1.0 / 5040)), vk(1.0 / 120)), vk(-1.0 / 6)), 1.0);
+        ch = fma(h2, fma(h2, fmak(h2, fmak(h2, V.lit_c8, V.lit_c6), V.lit_c4), -0.5), 1.0);
+        const double sinc = fma(h2, fmak(h2, fmak(h2, fmak(h2, V.lit_s9, V.lit_s7), V.lit_s5), V.lit_s3), 1.0);
         sh_over = 0.5 * V.dt * sinc;
     } else {
         const double wn = sqrt(w2), h = 0.5 * V.dt * wn;
@@ -265,8 +276,8 @@ __device__ __forceinline__ void free_body_step(const VehK &V, const double om[4]
     // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 is exact to rounding; a non-unit q (first tick of a caller-supplied
     // state) takes the general path.
     const double e = fma(n0, n0, fma(n1, n1, fma(n2, n2, n3 * n3))) - 1.0;
-    double inv = fma(e, fma(e, vk(0.375), -0.5), 1.0);
-    if (fabs(e) > vk(1.0e-6)) inv = fast_rsqrt(e + 1.0);
+    double inv = fma(e, fma(e, V.lit_375, -0.5), 1.0);
+    if (fabs(e) > V.lit_e_small) inv = fast_rsqrt(e + 1.0);
     q0 = n0 * inv; q1 = n1 * inv; q2 = n2 * inv; q3 = n3 * inv;
 }
 

@@ -359,6 +359,9 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     for (int i = 0; i < 3; ++i) { L.I[i] = vk(V.I[i]); L.inv_I[i] = vk(V.inv_I[i]); L.ikp[i] = vk(V.ikp[i]); }
     L.arm = vk(V.arm); L.inv_arm = vk(V.inv_arm); L.kappa = vk(V.kappa); L.inv_kappa = vk(V.inv_kappa);
     L.kf = vk(V.kf); L.inv_kf = vk(V.inv_kf);
+    L.lit_tiny = vk(V.lit_tiny); L.lit_h2_small = vk(V.lit_h2_small); L.lit_c8 = vk(V.lit_c8); L.lit_c6 = vk(V.lit_c6);
+    L.lit_c4 = vk(V.lit_c4); L.lit_s9 = vk(V.lit_s9); L.lit_s7 = vk(V.lit_s7); L.lit_s5 = vk(V.lit_s5); L.lit_s3 = vk(V.lit_s3);
+    L.lit_375 = vk(V.lit_375); L.lit_e_small = vk(V.lit_e_small);
 
     for (int k = 0; k < K; ++k) {
         if (phase == 0 && nrows > 0) {

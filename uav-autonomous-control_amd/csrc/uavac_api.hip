@@ -177,6 +177,10 @@ VehK uavac_make_vehk(const uavac_vehicle &V) {
     k.kp_roll = V.kp_roll; k.kp_pitch = V.kp_pitch; k.kp_yaw = V.kp_yaw;
     k.ikp[0] = V.inertia[0] * V.kp_p; k.ikp[1] = V.inertia[1] * V.kp_q; k.ikp[2] = V.inertia[2] * V.kp_r;
     k.hover_omega = std::sqrt(V.mass * V.g / (4.0 * V.kf));
+    k.lit_tiny = 2.2250738585072014e-308; k.lit_h2_small = 1.0e-3;
+    k.lit_c8 = 1.0 / 40320; k.lit_c6 = -1.0 / 720; k.lit_c4 = 1.0 / 24;
+    k.lit_s9 = 1.0 / 362880; k.lit_s7 = -1.0 / 5040; k.lit_s5 = 1.0 / 120; k.lit_s3 = -1.0 / 6;
+    k.lit_375 = 0.375; k.lit_e_small = 1.0e-6;
     k.F = V.inner_per_outer;
     k.ground = V.ground ? 1 : 0;
     k.ground_z = V.ground_z;

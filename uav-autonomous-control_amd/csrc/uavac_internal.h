@@ -117,6 +117,10 @@ struct VehK {
     double ikp[3];                   // I * kp_pqr: controller.py:128
     double hover_omega;
     double ground_zc, ground_k, ground_b, ground_z;   // contact starts at pz > ground_zc = ground_z - clearance; 1/tc^2, 2/tc
+    // the non-inline fp64 literals of the per-tick path (control_law.h): smallest normal, the large-angle threshold on
+    // (|w| dt / 2)^2, the Taylor coefficients of cos and sinc, 3/8 and the threshold of the renormalisation series.  They
+    // travel with the vehicle constants so that the rollout can put them into vector registers ONCE, ahead of its tick loop
+    double lit_tiny, lit_h2_small, lit_c8, lit_c6, lit_c4, lit_s9, lit_s7, lit_s5, lit_s3, lit_375, lit_e_small;
     int F;
     int ground;
 };
