@@ -30,9 +30,9 @@ __device__ __forceinline__ double vk(double x) {
     return x;
 }
 
-// fma(a, b, k) with the constant k of vk() as the addend, written as ONE v_fma_f64.  Left to itself the compiler makes a
-// v_fmac_f64 of it (destination = addend) and, the constant having to survive, copies it into the destination first: a
-// v_mov_b64 per Horner step, as expensive on this part as the FMA itself (tools/fp64_operand_probe.hip).
+// fma(a, b, k) with a register-resident constant k as the addend, as ONE three-address v_fma_f64: the two-address form
+// (v_fmac_f64, destination = addend) would have to copy a constant that must survive first, and a v_mov_b64 is as
+// expensive on this part as the FMA itself (tools/fp64_operand_probe.hip).
 __device__ __forceinline__ double fmak(double a, double b, double k) {
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
