@@ -45,7 +45,7 @@ int main(void) {
 
     uavac_vehicle V;
     uavac_vehicle_default(&V);
-    double state[UAVAC_STATE_ROWS];            /* [26][B] with B = 1 */
+    double state[UAVAC_STATE_ROWS];            /* [UAVAC_STATE_ROWS][B] with B = 1 */
     int32_t istate[UAVAC_ISTATE_ROWS];
     CHECK(uavac_state_init(ctx, &V, &wp[0][0], B, /*hover=*/1, state, istate));
     const int K = (int)offs[1] * V.inner_per_outer + 2000;          /* the whole trajectory + 2 s to settle */
