@@ -421,6 +421,54 @@ def main():
                                "steps_per_s_with_gather": C4_TOTAL * C4_TICKS / (c4_compute + gather_s),
                                "gather_verified": ok})
                 del gathered
+                # The same job with the gather BESIDE the rollout instead of after it: the trajectories are final when
+                # planning ends, so their transfer starts there, on a second stream, while the vehicles fly.  Reported next
+                # to the serial figures; a problem here is reported (`overlap_error`) but does not fail the run -- the
+                # verified serial gather above is the one that counts.
+                if gather_err is None and not rehearsal:
+                    side = torch.cuda.Stream(device=dev)
+
+                    def step4_overlapped():
+                        eng.replan(plan4)
+                        ticket = comm.gather_rows_begin(plan4.traj, dst=0, stream=side)
+                        fleet4.reset()
+                        for _ in range(C4_TICKS // CHUNK):
+                            fleet4.rollout(CHUNK, state_log=log4)
+                        got, cnt = comm.gather_finish(ticket)
+                        torch.cuda.synchronize()
+                        return got, cnt
+
+                    def everybody_fine(err):               # the same collective on every rank, whatever happened locally
+                        t = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=cdev)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        return int(t.item()) == 0
+
+                    over_err, same = None, True
+                    try:
+                        got, cnt = step4_overlapped()
+                        if rank == 0:
+                            same = sum(cnt) == got.shape[0] and bool((got[:cnt[0]] == plan4.traj[:cnt[0]]).all())
+                        del got
+                    except Exception as exc:
+                        over_err = f"{type(exc).__name__}: {exc}"
+                    if everybody_fine(over_err):
+                        barrier()
+                        g0 = time.perf_counter()
+                        try:
+                            for _ in range(2):
+                                got, cnt = step4_overlapped()
+                                del got
+                        except Exception as exc:
+                            over_err = f"{type(exc).__name__}: {exc}"
+                        barrier()
+                        over_s = (time.perf_counter() - g0) / 2
+                        t = torch.tensor([over_s], dtype=torch.float64, device=cdev)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        if rank == 0 and over_err is None:
+                            c4.update({"overlapped_ms": float(t.item()) * 1e3, "overlapped_verified": bool(same),
+                                       "steps_per_s_gather_overlapped": C4_TOTAL * C4_TICKS / float(t.item())})
+                    if rank == 0 and over_err is not None:
+                        c4["overlap_error"] = over_err
             except Exception as exc:                      # the timed result above must survive a collective problem
                 gather_err = f"{type(exc).__name__}: {exc}"
             watchdog.cancel()

@@ -643,3 +643,29 @@ def test_rollout_with_another_vehicle_matches_the_c_oracle(eng, nat, seed):
             assert col_err(slog[:, :, b].cpu().numpy(), s_ref) < 1e-9, (from_plan, b)
             assert col_err(clog[:, :, b].cpu().numpy(), c_ref) < 1e-9, (from_plan, b)
             assert int(fleet.trajectory_index[b]) == istate[0]
+
+
+def test_gather_beside_the_rollout_world_1(eng, nat):
+    """gather_rows_begin / gather_finish: the transfer of the (final) trajectories on a second stream while the vehicles
+    fly on the first -- same gathered rows as the synchronous call, and the flight is not disturbed."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    from uav_ac.fleet import RcclComm
+    buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+    eng.ctx.call("uavac_comm_unique_id", buf)
+    comm = RcclComm(eng, unique_id=bytes(buf.raw), world=1, rank=0)
+    try:
+        plan = eng.plan(mo.synthetic_missions(3000, 8), 3.0, 0.01)
+        ref_fleet, fleet = eng.fleet(plan), eng.fleet(plan)
+        ref_log, _ = ref_fleet.rollout(600, state_log=True)
+        want, counts = comm.gather_rows(plan.traj, dst=0)
+        side = torch.cuda.Stream(device=eng.device)
+        eng.replan(plan)                                           # rows rewritten on the main stream ...
+        ticket = comm.gather_rows_begin(plan.traj, dst=0, stream=side)      # ... and gathered once that is done
+        log, _ = fleet.rollout(600, state_log=True)                # enqueued behind the replan, beside the gather
+        got, counts2 = comm.gather_finish(ticket)
+        torch.cuda.synchronize()
+        assert counts2 == counts == [plan.total_rows] and torch.equal(got, want) and got.data_ptr() != plan.traj.data_ptr()
+        assert torch.equal(log, ref_log)
+    finally:
+        comm.close()

@@ -704,18 +704,39 @@ class RcclComm:
 
     def gather_rows(self, rows, dst: int = 0):
         """Ragged (n_r, C) f64 row blocks of all ranks -> (all_rows on dst | None, counts).  Synchronous."""
+        return self.gather_finish(self.gather_rows_begin(rows, dst))
+
+    def gather_rows_begin(self, rows, dst: int = 0, stream=None):
+        """Enqueue the gather and return at once: (the trajectories are final when planning ends, so their gather can run
+        beside the rollout instead of after it).  `stream`: a torch.cuda.Stream for the transfers; it first waits for
+        what the current stream has enqueued so far (the kernels that produce `rows`).  Default: the current stream.
+        Returns a ticket for `gather_finish`; `rows` must not be written before that."""
         e, torch = self.engine, self.engine._torch
         if not rows.is_cuda or rows.dtype != torch.float64 or rows.dim() != 2:
             raise ValueError("rows must be a 2-D float64 GPU tensor")
         rows = rows.contiguous()
-        counts = self.counts(rows.shape[0])
-        out = None
-        if self.rank == dst:
-            out = torch.empty((sum(counts), rows.shape[1]), dtype=torch.float64, device=e.device)
-        e._bind_stream()
-        e.ctx.call("uavac_gather_rows_dev", self._h, _ptr(rows), int(rows.shape[0]), int(rows.shape[1]),
-                   (C.c_int64 * self.world)(*counts), int(dst), _ptr(out))
-        e.ctx.call("uavac_comm_finish", self._h)
+        here = torch.cuda.current_stream(e.device)
+        stream = here if stream is None else stream
+        if stream is not here:
+            stream.wait_stream(here)
+        with torch.cuda.stream(stream):
+            counts = self.counts(rows.shape[0])              # a tiny synchronous all-gather on that stream
+            out = None
+            if self.rank == dst:
+                out = torch.empty((sum(counts), rows.shape[1]), dtype=torch.float64, device=e.device)
+            e._bind_stream()
+            e.ctx.call("uavac_gather_rows_dev", self._h, _ptr(rows), int(rows.shape[0]), int(rows.shape[1]),
+                       (C.c_int64 * self.world)(*counts), int(dst), _ptr(out))
+        return (stream, out, counts, rows)
+
+    def gather_finish(self, ticket):
+        """Wait for a gather started with `gather_rows_begin` -> (all_rows on dst | None, counts)."""
+        e, torch = self.engine, self.engine._torch
+        stream, out, counts, _rows = ticket
+        with torch.cuda.stream(stream):
+            e._bind_stream()
+            e.ctx.call("uavac_comm_finish", self._h)
+        e._bind_stream()                                      # back on the caller's stream
         return out, counts
 
     def loopback(self, src):
