@@ -13,6 +13,9 @@ for p in (REPO, PKG):
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# A test run on a fresh checkout builds the HIP library itself (the product only does so when asked: uav_ac/_native.py)
+os.environ.setdefault("UAVAC_AUTOBUILD", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
