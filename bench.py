@@ -35,6 +35,7 @@ PKG = os.path.join(ROOT, "uav-autonomous-control_amd")
 for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
+os.environ.setdefault("UAVAC_AUTOBUILD", "1")       # a never-built checkout compiles the HIP library on first use (no fallback)
 
 import numpy as np  # noqa: E402
 
