@@ -36,6 +36,12 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("UAVAC_AUTOBUILD", "1")       # a never-built checkout compiles the HIP library on first use (no fallback)
+_LIB = os.path.join(PKG, "lib", "libuavac.so")
+if not os.path.exists(_LIB) and int(os.environ.get("LOCAL_RANK", "0")) != 0:
+    for _ in range(1200):                           # ... once: the other ranks of the node wait for local rank 0's build
+        if os.path.exists(_LIB):
+            break
+        time.sleep(0.5)
 
 import numpy as np  # noqa: E402
 
