@@ -40,6 +40,7 @@ _LIB = os.path.join(PKG, "lib", "libuavac.so")
 if not os.path.exists(_LIB) and int(os.environ.get("LOCAL_RANK", "0")) != 0:
     for _ in range(1200):                           # ... once: the other ranks of the node wait for local rank 0's build
         if os.path.exists(_LIB):
+            time.sleep(5.0)                         # the linker may still be writing it
             break
         time.sleep(0.5)
 
