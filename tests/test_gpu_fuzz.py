@@ -77,3 +77,49 @@ def test_random_ragged_batch_against_the_oracles(eng, it):
         if np.isfinite(s_ref).all() and np.abs(s_ref[:, 10:13]).max() < 40.0:      # a vehicle that has not tumbled away
             assert col_err(s, s_ref) < 1e-7, (it, b)
             assert col_err(logs[False][1][:, :, int(b)].cpu().numpy(), c_ref) < 1e-7, (it, b)
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_random_takeoffs_obstacles_and_log_combinations(eng, it):
+    """Vehicles that start on the ground plane with stopped rotors (the reference's true start) below missions drawn at
+    random, a handful of random cuboids tested on every tick, every combination of logs: the flags, the ground bookkeeping
+    and the states do not depend on which logs are taken (the obstacle test moves between the waves with them), the flags
+    equal a recomputation from the logged positions, and two lanes equal the C oracle."""
+    import torch
+    from uav_ac import _native as nat
+    from oracle import c_oracle as cc
+    rng = np.random.default_rng(7000 + it)
+    B = int(rng.integers(1, 200))
+    missions = _missions(rng, B)
+    for w in missions:                                            # from the ground (z = -0.02: the body rests on the plane)
+        w[0, 2] = -0.02
+        w[1:, 2] = np.minimum(w[1:, 2], -1.0)
+    velocity, dt = float(rng.uniform(0.8, 2.5)), 0.01
+    rb = eng.plan_ragged(missions, velocity, dt)
+    V, Vc = nat.Vehicle.default(), cc.Vehicle.default()
+    V.ground = Vc.ground = 1
+    n_obs = int(rng.integers(1, 12))
+    lo = np.stack([rng.uniform(0, 20, n_obs), rng.uniform(0, 12, n_obs), -rng.uniform(2, 6, n_obs)], axis=1)
+    size = rng.uniform(0.5, 4.0, (n_obs, 3))
+    boxes = np.stack([lo[:, 0], lo[:, 0] + size[:, 0], lo[:, 1], lo[:, 1] + size[:, 1], lo[:, 2], lo[:, 2] + size[:, 2]], axis=1)
+    K = 1500
+    results = []
+    for state_log, cmd_log in ((True, False), (False, False), (True, True), (False, True)):
+        fleet = eng.fleet(rb, vehicle=V, hover=False, from_plan=bool(rng.integers(0, 2)))
+        slog, clog = fleet.rollout(K, state_log=state_log or None, cmd_log=cmd_log or None, aabbs=boxes)
+        results.append((fleet.state[:26].clone(), fleet.istate.clone(), slog))
+    for st, ist, _ in results[1:]:
+        assert torch.equal(st, results[0][0]) and torch.equal(ist, results[0][1])
+    slog = results[0][2]
+    inside = torch.zeros(B, dtype=torch.bool, device=slog.device)
+    for c in boxes:
+        inside |= ((slog[:, 0] >= c[0]) & (slog[:, 0] <= c[1]) & (slog[:, 1] >= c[2]) & (slog[:, 1] <= c[3]) &
+                   (slog[:, 2] >= c[4]) & (slog[:, 2] <= c[5])).any(dim=0)
+    assert torch.equal(results[0][1][2].bool(), inside)
+    for b in rng.choice(B, size=min(B, 2), replace=False):
+        traj = rb.mission(int(b))
+        state, istate = cc.initial_state(traj[0, 0:3], Vc, hover=False)
+        s_ref, _ = cc.rollout(traj, state, istate, K, Vc, aabbs=boxes)
+        if np.isfinite(s_ref).all() and np.abs(s_ref[:, 10:13]).max() < 40.0:
+            assert col_err(slog[:, :, int(b)].cpu().numpy(), s_ref) < 1e-7, (it, b)
+            assert results[0][1][:, int(b)].cpu().tolist() == istate.tolist(), (it, b)
