@@ -6,6 +6,11 @@ controller + dynamics ticks, on synthetic missions (SURVEY.md 8(d) generator).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started WITHOUT a launcher (`python bench.py --gpus N`, N > 1, no WORLD_SIZE in the environment) it launches its N ranks
+itself: the parent touches no GPU, checks that N GPUs are visible (exit 2 with a message otherwise), starts N children
+with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, forwards rank 0's single JSON line and
+exits with the worst exit code of the children.
+
 A "step" is one whole job over one batch: the planning chain (times/row counts, offsets, coefficient solve,
 sampler; ONE call into the C ABI), vehicle reset, then 10 000 control ticks as 10 launches of 1 000 ticks whose
 6.8 GB state log buffer is reused.  Inputs (waypoints) are resident in HBM before the timed region.  The batch
@@ -17,7 +22,9 @@ the HBM peak with the algorithmic 112.8 B per UAV tick of SURVEY.md 8(d), on the
 measured with HIP events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle timed
 on this box's host cores on a bounded sample.  `config4` is BASELINE.json configs[3] run on the same N GPUs
 (262 144 UAVs in total = strong scaling, 8-segment missions, 5 000 ticks, final gather of the trajectories to
-rank 0 over RCCL timed and verified) with compute-only and compute+gather rates side by side.
+rank 0 over RCCL timed and verified) with compute-only and compute+gather rates side by side, for the gather of the
+ROWS (20.8 GB into the root's links) and for the gather of the PLAN (0.4 GB; the root re-samples the peers' rows from
+it, bit-identical -- verified against the row gather in the same run).
 
 Exit status: 0 only when everything asked for ran; a stalled or failed gather prints the line with
 `gather_error` and exits 3.
@@ -39,8 +46,7 @@ os.environ.setdefault("UAVAC_AUTOBUILD", "1")       # a never-built checkout com
 _LIB = os.path.join(PKG, "lib", "libuavac.so")
 if not os.path.exists(_LIB) and int(os.environ.get("LOCAL_RANK", "0")) != 0:
     for _ in range(1200):                           # ... once: the other ranks of the node wait for local rank 0's build
-        if os.path.exists(_LIB):
-            time.sleep(5.0)                         # the linker may still be writing it
+        if os.path.exists(_LIB):                    # (the Makefile links to a temporary name and renames: it is complete)
             break
         time.sleep(0.5)
 
@@ -126,6 +132,76 @@ def cpu_baseline(eng=None, wps=None):
     return out
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks from here.  The parent never touches a GPU
+    (counting devices does not initialise one); children are separate processes, nothing is exec'ed."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.launch_check:
+        import torch
+        have = torch.cuda.device_count()
+        shared = os.environ.get("UAVAC_BENCH_REHEARSAL") == "1"
+        if have < (1 if shared else n):
+            print(f"bench.py: --gpus {n} but {have} GPU(s) visible; refusing to print a line for fewer GPUs than asked for",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # rank 0's stdout carries the JSON line; whatever the other ranks print goes to this process's stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    deadline = None
+    codes = [procs[0].returncode] + [None] * (n - 1)
+    while any(c is None for c in codes):
+        for r in range(1, n):
+            if codes[r] is None:
+                codes[r] = procs[r].poll()
+        if any(c not in (None, 0) for c in codes) or all(c is not None for c in codes[:1]):
+            deadline = deadline or time.time() + 120.0          # rank 0 is done (or somebody failed): the rest gets two minutes
+        if deadline and time.time() > deadline:
+            for r in range(1, n):
+                if codes[r] is None:
+                    procs[r].kill()                             # exactly the children started above
+                    codes[r] = procs[r].wait() or 9
+        time.sleep(0.05)
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    worst = 0
+    for c in codes:
+        c = 128 - c if c < 0 else c                             # killed by a signal
+        worst = max(worst, c)
+    return worst
+
+
+def launch_check(args):
+    """`--launch-check`: the rank side of the self-launcher without any GPU work -- rendezvous over gloo, one barrier,
+    one reduction, the single JSON line from rank 0.  What the CPU test suite runs through `self_launch`."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    fail = os.environ.get("UAVAC_BENCH_FAIL_RANK")
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(t.item()),
+                          "local_ranks_seen": world, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if fail is not None and int(fail) == rank:
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,7 +212,15 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed diagnostic passes (per-launch table, "
                                                              "flyable-distribution rate)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous + one JSON line, no GPU work (tests of the "
+                                                                "self-launcher)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))          # no launcher around us: be the launcher (before any GPU call)
+    if args.launch_check:
+        return launch_check(args)
 
     import torch
     import torch.distributed as dist
@@ -145,7 +229,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:                                 # never a line whose n_gpus differs from what was asked for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # UAVAC_BENCH_REHEARSAL=1: several ranks share one GPU (RCCL refuses that), the process group is gloo and the gather
     # takes the host path of uav_ac.fleet.gather_rows on a slice of the rows.  It exists to walk the N > 1 control flow of
@@ -177,7 +261,18 @@ def main():
     # The row buffer is chosen among PLACEMENT_TRIALS allocations by timing the sampler on each (Engine.plan, DESIGN K2: whether
     # the rows stream out at ~6.0 or ~5.1 TB/s is a property of where the buffer lies, for as long as it lives).  Untimed
     # set-up, reported in the line.
-    plan = eng.plan(wps, VELOCITY, DT, placement_trials=PLACEMENT_TRIALS)      # allocates; also the first warm-up
+    plan = eng.plan(wps, VELOCITY, DT)                   # allocates; also the first warm-up
+    # the planning chain into the FIRST allocation of the row buffer -- what a caller gets who does not search
+    for _ in range(5):
+        eng.replan(plan)
+    fa0, fa1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fa0.record()
+    for _ in range(10):
+        eng.replan(plan)
+    fa1.record()
+    fa1.synchronize()
+    plan_first_alloc_s = fa0.elapsed_time(fa1) * 1e-3 / 10
+    eng.place_rows(plan, PLACEMENT_TRIALS)              # the search (untimed set-up; keeps the fastest candidate)
     fleet = eng.fleet(plan)
     log = torch.empty((CHUNK, 13, B), dtype=torch.float64, device=dev)
     n_chunks = TICKS // CHUNK
@@ -286,6 +381,9 @@ def main():
                          "rollout_source_sha": rollout_source_sha()},
             "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
                         "ms_solve_plus_sample": plan_avg_s * 1e3,
+                        "ms_solve_plus_sample_first_allocation": plan_first_alloc_s * 1e3,
+                        "value_first_allocation": B * m / plan_first_alloc_s,
+                        "frac_first_allocation": plan.algorithmic_bytes / plan_first_alloc_s / 1e9 / HBM_PEAK_GBS,
                         "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
@@ -357,29 +455,47 @@ def main():
         fleet4 = eng.fleet(plan4)
         log4 = torch.empty((CHUNK, 13, B4), dtype=torch.float64, device=dev)
 
-        def step4():
-            eng.replan(plan4)
+        def fly4():
             fleet4.reset()
             for _ in range(C4_TICKS // CHUNK):
                 fleet4.rollout(CHUNK, state_log=log4)
 
+        def step4():
+            eng.replan(plan4)
+            fly4()
+
+        def timed(fn, reps):
+            """max over ranks of the mean wall time of `fn`, bracketed by barriers"""
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            barrier()
+            dt_ = (time.perf_counter() - t0) / reps
+            if multi:
+                t = torch.tensor([dt_], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_ = float(t.item())
+            return dt_
+
         step4()
-        barrier()
-        n4 = 3
-        t0 = time.perf_counter()
-        for _ in range(n4):
-            step4()
-        barrier()
-        c4_compute = (time.perf_counter() - t0) / n4
-        if multi:
-            t = torch.tensor([c4_compute], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            c4_compute = float(t.item())
+        c4_compute = timed(step4, 3)
+        # what re-sampling this rank's rows from its plan costs (at N = 1: all 262 144 missions = what the root of the plan
+        # gather pays at any N, on top of its own share of the flight)
+        a, b = ev(), ev()
+        eng.sample(plan4)
+        a.record()
+        for _ in range(3):
+            eng.sample(plan4)
+        b.record()
+        torch.cuda.synchronize()
         c4 = {"workload": "BASELINE.json configs[3]: 262144 UAVs in total (strong scaling), 8-segment missions, plan + "
                           "5000 fused ticks (5 launches x 1000, state logged), trajectories gathered to rank 0",
               "batch_total": C4_TOTAL, "batch_per_gpu": B4, "segments": C4_SEGMENTS, "ticks": C4_TICKS,
               "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
-              "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel()}
+              "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel(),
+              "resample_rank0_rows_ms": a.elapsed_time(b) / 3,
+              "plan_bytes_rank0": int(plan4.B * C4_SEGMENTS * 204), "row_bytes_rank0": int(plan4.total_rows * 88)}
         if rank == 0:
             out["config4"] = c4
 
@@ -393,25 +509,34 @@ def main():
             watchdog = threading.Timer(GATHER_TIMEOUT_S, bail)
             watchdog.daemon = True
             watchdog.start()
+
+            def everybody_fine(err):               # the same collective on every rank, whatever happened locally
+                t = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return int(t.item()) == 0
+
             try:
+                from uav_ac.fleet import gather_plan, gather_rows
+                SLICE = 200000                             # rehearsal: rows per rank that cross gloo (control flow only)
                 if rehearsal:
-                    from uav_ac.fleet import gather_rows
-                    mine = plan4.traj[:200000].cpu()           # a slice through gloo: control flow only
-                    barrier()
-                    g0 = time.perf_counter()
-                    gathered, counts = gather_rows(mine, dst=0)
-                    barrier()
-                    gather_s = time.perf_counter() - g0
-                    if rank == 0:
-                        gathered = gathered.to(dev)
+                    def rows_gather():
+                        g, c = gather_rows(plan4.traj[:SLICE].cpu(), dst=0)
+                        return (g.to(dev) if g is not None else None), c
+
+                    def plan_gather():
+                        return gather_plan(plan4, dst=0, engine=eng)
                 else:
                     comm = RcclComm(eng)                   # ncclCommInitRank behind the C ABI; id travels over the process group
-                    comm.gather_rows(plan4.traj[:1024], dst=0)      # connection set-up is not part of the timed gather
-                    barrier()
-                    g0 = time.perf_counter()
-                    gathered, counts = comm.gather_rows(plan4.traj, dst=0)
-                    barrier()
-                    gather_s = time.perf_counter() - g0
+                    comm.gather_rows(plan4.traj[:1024], dst=0)      # connection set-up is not part of any timed gather
+
+                    def rows_gather():
+                        return comm.gather_rows(plan4.traj, dst=0)
+
+                    def plan_gather():
+                        return comm.gather_plan(plan4, dst=0)
+
+                # ---- the gather of the ROWS: once untimed (allocation, verification), then timed
+                gathered, counts = rows_gather()
                 if rank == 0:
                     own = counts[0]
                     ok = sum(counts) == gathered.shape[0] and bool((gathered[:own] == plan4.traj[:own]).all())
@@ -422,61 +547,83 @@ def main():
                     ok = ok and bool(np.array_equal(got, first))
                     if not ok:
                         gather_err = "gathered rows do not match"
+                holder = []
+                gather_s = timed(lambda: holder.append(rows_gather()) or holder.clear(), 1)
+                if rank == 0:
                     if rehearsal:
                         c4["REHEARSAL"] = "ranks share one GPU, gloo, a 200000-row slice per rank: control flow only, not a measurement"
                     c4.update({"gather_ms": gather_s * 1e3, "gather_rows_total": int(sum(counts)),
                                "gather_GBps_into_root": (sum(counts) - counts[0]) * 88 / gather_s / 1e9,
                                "steps_per_s_with_gather": C4_TOTAL * C4_TICKS / (c4_compute + gather_s),
                                "gather_verified": ok})
-                del gathered
+
+                # ---- the gather of the PLAN (coefficients, durations, rows per spline; the root re-samples): once untimed,
+                # verified against the rows the row gather delivered, then timed
+                gp, pcounts = plan_gather()
+                if rank == 0:
+                    total_rows = sum(pcounts)
+                    if rehearsal:                          # only a slice of every peer's rows crossed gloo
+                        offs_full = np.concatenate([[0], np.cumsum(pcounts)])
+                        same = gp.traj.shape[0] == total_rows and bool((gp.traj[:pcounts[0]] == plan4.traj).all())
+                        for r in range(world):
+                            n = min(SLICE, pcounts[r])
+                            same = same and bool((gp.traj[offs_full[r]:offs_full[r] + n] == gathered[offs[r]:offs[r] + n]).all())
+                    else:
+                        same = pcounts == counts and gp.traj.shape == gathered.shape and bool((gp.traj == gathered).all())
+                    same = same and bool((gp.coeffs[:plan4.B] == plan4.coeffs).all()) and \
+                        bool((gp.row_offsets[:plan4.B + 1] == plan4.row_offsets).all())
+                    if not same:
+                        gather_err = gather_err or "rows re-sampled from the gathered plan differ from the gathered rows"
+                    c4["plan_gather_verified"] = bool(same)
+                    c4["plan_gather_bytes_into_root"] = int((C4_TOTAL - B4) * C4_SEGMENTS * 204)
+                del gathered, gp
+                plan_s = timed(lambda: holder.append(plan_gather()) or holder.clear(), 2)
+                if rank == 0:
+                    c4.update({"plan_gather_ms": plan_s * 1e3,
+                               "steps_per_s_with_plan_gather": C4_TOTAL * C4_TICKS / (c4_compute + plan_s)})
+
                 # The same job with the gather BESIDE the rollout instead of after it: the trajectories are final when
-                # planning ends, so their transfer starts there, on a second stream, while the vehicles fly.  Reported next
-                # to the serial figures; a problem here is reported (`overlap_error`) but does not fail the run -- the
-                # verified serial gather above is the one that counts.
+                # planning ends, so their transfer (rows), or the transfer of the plan and the root's re-sampling, starts
+                # there on a second stream while the vehicles fly.  A problem here is reported (`overlap_error`) but does
+                # not fail the run -- the verified serial gathers above are the ones that count.
                 if gather_err is None and not rehearsal:
                     side = torch.cuda.Stream(device=dev)
 
-                    def step4_overlapped():
-                        eng.replan(plan4)
-                        ticket = comm.gather_rows_begin(plan4.traj, dst=0, stream=side)
-                        fleet4.reset()
-                        for _ in range(C4_TICKS // CHUNK):
-                            fleet4.rollout(CHUNK, state_log=log4)
-                        got, cnt = comm.gather_finish(ticket)
-                        torch.cuda.synchronize()
-                        return got, cnt
+                    def overlapped(begin):
+                        def run():
+                            eng.replan(plan4)
+                            ticket = begin(plan4, side)
+                            fly4()
+                            got, cnt = comm.gather_finish(ticket)
+                            torch.cuda.synchronize()
+                            return got, cnt
+                        return run
 
-                    def everybody_fine(err):               # the same collective on every rank, whatever happened locally
-                        t = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=cdev)
-                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                        return int(t.item()) == 0
-
-                    over_err, same = None, True
-                    try:
-                        got, cnt = step4_overlapped()
-                        if rank == 0:
-                            same = sum(cnt) == got.shape[0] and bool((got[:cnt[0]] == plan4.traj[:cnt[0]]).all())
-                        del got
-                    except Exception as exc:
-                        over_err = f"{type(exc).__name__}: {exc}"
-                    if everybody_fine(over_err):
-                        barrier()
-                        g0 = time.perf_counter()
+                    variants = (("rows", overlapped(lambda p, st: comm.gather_rows_begin(p.traj, dst=0, stream=st)),
+                                 "overlapped_ms", "steps_per_s_gather_overlapped", "overlapped_verified"),
+                                ("plan", overlapped(lambda p, st: comm.gather_plan_begin(p, dst=0, stream=st)),
+                                 "plan_overlapped_ms", "steps_per_s_plan_gather_overlapped", "plan_overlapped_verified"))
+                    for kind, run, k_ms, k_rate, k_ok in variants:
+                        over_err, same = None, True
                         try:
-                            for _ in range(2):
-                                got, cnt = step4_overlapped()
-                                del got
+                            got, cnt = run()
+                            if rank == 0:
+                                rows_ = got if kind == "rows" else got.traj
+                                same = sum(cnt) == rows_.shape[0] and bool((rows_[:cnt[0]] == plan4.traj[:cnt[0]]).all())
+                            del got
                         except Exception as exc:
                             over_err = f"{type(exc).__name__}: {exc}"
-                        barrier()
-                        over_s = (time.perf_counter() - g0) / 2
-                        t = torch.tensor([over_s], dtype=torch.float64, device=cdev)
-                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                        if rank == 0 and over_err is None:
-                            c4.update({"overlapped_ms": float(t.item()) * 1e3, "overlapped_verified": bool(same),
-                                       "steps_per_s_gather_overlapped": C4_TOTAL * C4_TICKS / float(t.item())})
-                    if rank == 0 and over_err is not None:
-                        c4["overlap_error"] = over_err
+                        if everybody_fine(over_err):
+                            try:
+                                over_s = timed(lambda: holder.append(run()) or holder.clear(), 2)
+                            except Exception as exc:
+                                over_err, over_s = f"{type(exc).__name__}: {exc}", float("nan")
+                            if rank == 0 and over_err is None:
+                                c4.update({k_ms: over_s * 1e3, k_ok: bool(same), k_rate: C4_TOTAL * C4_TICKS / over_s})
+                        if rank == 0 and over_err is not None:
+                            c4["overlap_error"] = f"{kind}: {over_err}"
+                        if not everybody_fine(over_err):
+                            break
             except Exception as exc:                      # the timed result above must survive a collective problem
                 gather_err = f"{type(exc).__name__}: {exc}"
             watchdog.cancel()

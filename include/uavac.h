@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UAVAC_VERSION 200 /* 0.2.0: uavac_vehicle grew the ground-plane fields, istate has 4 rows */
+#define UAVAC_VERSION 300 /* 0.3.0: plan gather, log pitch, row offsets from row counts; 0.2.0: ground-plane fields, istate has 4 rows */
 
 #define UAVAC_OK 0
 #define UAVAC_EINVAL (-1)    /* bad shape / size / null pointer                    */
@@ -172,12 +172,21 @@ int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const 
  * column when yaw != NULL, + the missions' first headings when first_yaw != NULL) -- four kernel
  * launches back to back, no host code in between.  The row
  * buffer must have been sized by the caller: traj holds traj_capacity_rows rows (yaw as many
- * values); when the plan needs more, nothing is written and flag 2 is raised (uavac_take_flags).
+ * values); when the plan needs more it is refused AS A WHOLE and flag 2 is raised (uavac_take_flags):
+ * times, seg_rows, row_offsets, coeffs, status, traj, yaw and first_yaw all keep what they held, so the
+ * previous plan stays consistent and flyable (times / row counts / offsets are computed into ctx scratch
+ * and copied into the caller's arrays by a device-side commit only when the rows fit).
  * Typical use: size the buffers once with uavac_minsnap_row_counts_dev, then re-plan in place. */
 int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                            double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs,
                            int32_t *status, double *traj, int64_t traj_capacity_rows, double *yaw,
                            double *first_yaw);
+
+/* row_offsets [B+1] from per-segment row counts that exist already -- the second half of
+ * uavac_minsnap_row_counts_dev on its own, for a plan whose seg_rows [B][m] came from elsewhere (the
+ * peers' plans after uavac_gather_plan_dev): exclusive prefix sum of the per-mission totals
+ * (sum of len(np.arange(0, T, dt)) over the mission's splines, minimum_snap.py:104). */
+int uavac_minsnap_row_offsets_dev(uavac_ctx *ctx, const int32_t *seg_rows, int B, int m, int64_t *row_offsets);
 
 /* Ragged batches: missions with different numbers of waypoints in one call -- what a fleet of MinimumSnap objects with
  * paths of different lengths is (minimum_snap.py:13-57 takes any path), and what the obstacle loop (:63-95) produces as
@@ -460,6 +469,22 @@ int uavac_gather_counts(uavac_ctx *ctx, void *nccl_comm, int64_t n_rows, int64_t
  * reports asynchronous RCCL errors. */
 int uavac_gather_rows_dev(uavac_ctx *ctx, void *nccl_comm, const double *rows, int64_t n_rows,
                           int row_elems, const int64_t *counts, int root, double *out);
+/* Gather of the PLAN instead of the rows.  The rows of a mission are a deterministic, bit-reproducible function of its
+ * coefficients and per-segment row counts (uavac_minsnap_sample_dev), 204 B per segment against ~10 KB of rows: the peers
+ * send coeffs [n_segments][8][3], times [n_segments] (optional: NULL on every rank or on none) and seg_rows [n_segments]
+ * to the root in ONE grouped launch (three ncclSend per peer / three ncclRecv per peer on the root), the root then calls
+ * uavac_minsnap_row_offsets_dev + uavac_minsnap_sample_dev on the gathered plan and holds the very rows the peers hold,
+ * written at its own HBM rate instead of arriving at the rate of its xGMI links (BASELINE config 4: 0.4 GB instead of
+ * 20.8 GB through the root's seven links).  seg_counts is the HOST array of uavac_gather_counts(n_segments); rank r's block
+ * lands at segment offset sum(seg_counts[:r]) of the *_out arrays (device, root only).  Enqueued on the ctx stream;
+ * uavac_comm_finish synchronises.  (No reference counterpart, like the row gather.) */
+int uavac_gather_plan_dev(uavac_ctx *ctx, void *nccl_comm, const double *coeffs, const double *times,
+                          const int32_t *seg_rows, int64_t n_segments, const int64_t *seg_counts, int root,
+                          double *coeffs_out, double *times_out, int32_t *seg_rows_out);
+/* NCCL_VERSION_CODE of the rccl.h this library was built with, and ncclGetVersion() of the RCCL the process has
+ * mapped (in a Python process: the one bundled with torch).  uavac_comm_init_rank refuses a different major version
+ * or a runtime older than 2.10; only entry points stable since then are used, so the minor versions may differ. */
+int uavac_comm_versions(int *built_with, int *runtime);
 int uavac_comm_finish(uavac_ctx *ctx, void *nccl_comm);
 /* Self-test of the transport on a single GPU: src [n] -> dst [n] through ncclSend + ncclRecv with
  * this rank as its own peer, grouped exactly like the gather (enqueued; then uavac_comm_finish). */

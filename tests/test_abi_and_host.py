@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uavac.h but not exported"
     assert sorted(nat.exported_symbols()) == declared       # the ctypes table covers the header exactly
-    assert lib.uavac_version() == nat.VERSION == 200
+    assert lib.uavac_version() == nat.VERSION == 300
 
 
 def test_vehicle_struct_layout_and_defaults():

@@ -43,6 +43,9 @@ def test_bench_multi_gpu_path_on_real_rccl_at_world_1():
     c4 = line["config4"]
     assert c4["batch_total"] == 262144 and c4["batch_per_gpu"] == 262144 and c4["gather_verified"] is True
     assert c4["gather_rows_total"] == c4["rows_rank0"] and c4["gather_ms"] > 0
+    # round 3: the gather of the plan + re-sampling on the root, verified bit for bit against the gathered rows
+    assert c4["plan_gather_verified"] is True and c4["plan_gather_ms"] > 0 and c4["steps_per_s_with_plan_gather"] > 0
+    assert c4["plan_overlapped_verified"] is True and "overlap_error" not in c4
 
 
 def test_rccl_world1_gather_and_loopback(eng, nat):

@@ -1,0 +1,161 @@
+"""GPU tests of round 3: the gather of the PLAN (root re-samples the peers' rows, bit-identical to the row gather), the
+atomic refusal of a re-plan that does not fit, the yaw scan of a fleet whose plan is re-solved in flight, row offsets from
+row counts, and the RCCL version guard."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from uav_ac import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from uav_ac.fleet import Engine
+    return Engine("cuda:0")
+
+
+def _missions(B, m):
+    from oracle import minsnap_oracle as mo
+    return mo.synthetic_missions(B, m)
+
+
+def test_row_offsets_from_row_counts(eng, nat):
+    import torch
+    plan = eng.plan(_missions(1000, 5), 3.0, 0.01)
+    ro = torch.full_like(plan.row_offsets, -1)
+    eng._bind_stream()
+    eng.ctx.call("uavac_minsnap_row_offsets_dev", C.c_void_p(plan.seg_rows.data_ptr()), plan.B, plan.m, C.c_void_p(ro.data_ptr()))
+    assert torch.equal(ro, plan.row_offsets)
+    with pytest.raises(nat.UavacError):
+        eng.ctx.call("uavac_minsnap_row_offsets_dev", C.c_void_p(plan.seg_rows.data_ptr()), plan.B, plan.m, None)
+
+
+def test_plan_from_parts_resamples_bit_identical_rows_at_any_alignment(eng):
+    """What the root of the plan gather does: rows from (coefficients, rows per spline, dt) alone.  The row buffer of the
+    re-sampled plan starts elsewhere (other 128-byte phase of every mission): the sampler's store pattern follows the
+    address, the values do not."""
+    import torch
+    plan = eng.plan(_missions(777, 8), 3.0, 0.01)
+    again = eng.plan_from_parts(plan.coeffs.clone(), plan.times.clone(), plan.seg_rows.clone(), 8, 3.0, 0.01)
+    assert again.total_rows == plan.total_rows and torch.equal(again.row_offsets, plan.row_offsets)
+    assert torch.equal(again.traj, plan.traj) and torch.equal(again.first_yaw, plan.first_yaw)
+    # a tail of the batch, into a preallocated buffer, rows landing at another line phase
+    k = 5
+    big = torch.full((plan.total_rows + 3, 11), -1.0, dtype=torch.float64, device=eng.device)
+    tail = eng.plan_from_parts(plan.coeffs[k:], None, plan.seg_rows[k:], 8, 3.0, 0.01, traj=big[3:])
+    r0 = int(plan.row_offsets[k])
+    assert tail.total_rows == plan.total_rows - r0
+    assert torch.equal(tail.traj, plan.traj[r0:]) and bool((big[:3] == -1.0).all())
+    # a fleet flies the re-assembled plan like the original (start positions come from the coefficients)
+    f0, f1 = eng.fleet(plan, from_plan=True), eng.fleet(again, from_plan=True)
+    f0.rollout(700)
+    f1.rollout(700)
+    assert torch.equal(f0.state, f1.state) and torch.equal(f0.istate, f1.istate)
+
+
+def test_plan_gather_world1_equals_row_gather(eng, nat):
+    """The RCCL calls of the plan gather at world 1 (the root's own block) + the root's re-sampling: the rows equal what the
+    row gather delivers, bit for bit."""
+    import torch
+    from uav_ac.fleet import RcclComm
+    buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+    eng.ctx.call("uavac_comm_unique_id", buf)
+    comm = RcclComm(eng, unique_id=bytes(buf.raw), world=1, rank=0)
+    try:
+        plan = eng.plan(_missions(3000, 8), 3.0, 0.01)
+        rows, counts = comm.gather_rows(plan.traj, dst=0)
+        gp, pcounts = comm.gather_plan(plan, dst=0)
+        assert pcounts == counts == [plan.total_rows]
+        assert gp.coeffs.data_ptr() != plan.coeffs.data_ptr()
+        assert torch.equal(gp.traj, rows) and torch.equal(gp.coeffs, plan.coeffs) and torch.equal(gp.times, plan.times)
+        assert torch.equal(gp.seg_rows, plan.seg_rows) and torch.equal(gp.row_offsets, plan.row_offsets)
+        assert torch.equal(gp.first_yaw, plan.first_yaw)
+        # beside other work on a second stream
+        side = torch.cuda.Stream(device=eng.device)
+        ticket = comm.gather_plan_begin(plan, dst=0, stream=side)
+        fleet = eng.fleet(plan)
+        fleet.rollout(200)
+        gp2, _ = comm.gather_finish(ticket)
+        torch.cuda.synchronize()
+        assert torch.equal(gp2.traj, plan.traj)
+        # argument checking happens before anything is enqueued
+        cnt = (C.c_int64 * 1)(plan.B * plan.m)
+        p = lambda t: C.c_void_p(t.data_ptr())     # noqa: E731
+        with pytest.raises(nat.UavacError) as e:   # counts[rank] must be this rank's segment count
+            eng.ctx.call("uavac_gather_plan_dev", comm._h, p(plan.coeffs), p(plan.times), p(plan.seg_rows), 5, cnt, 0,
+                         p(gp.coeffs), p(gp.times), p(gp.seg_rows))
+        assert e.value.code == nat.EINVAL
+        with pytest.raises(nat.UavacError) as e:   # times on one side only
+            eng.ctx.call("uavac_gather_plan_dev", comm._h, p(plan.coeffs), None, p(plan.seg_rows), plan.B * plan.m, cnt, 0,
+                         p(gp.coeffs), p(gp.times), p(gp.seg_rows))
+        assert e.value.code == nat.EINVAL
+        with pytest.raises(nat.UavacError):
+            eng.ctx.call("uavac_gather_plan_dev", comm._h, p(plan.coeffs), p(plan.times), p(plan.seg_rows), plan.B * plan.m, cnt, 2,
+                         p(gp.coeffs), p(gp.times), p(gp.seg_rows))
+    finally:
+        comm.close()
+
+
+def test_rccl_versions_are_reported_and_compatible(nat):
+    built, rt = C.c_int(0), C.c_int(0)
+    assert nat.lib().uavac_comm_versions(C.byref(built), C.byref(rt)) == 0
+    assert built.value >= 21000 and rt.value >= 21000          # 2.10+
+    assert built.value // 10000 == rt.value // 10000            # same major: what uavac_comm_init_rank insists on
+
+
+def test_refused_replan_leaves_the_whole_plan_untouched_and_flyable(eng):
+    """round-2 ADVICE (medium): a re-plan that needs more rows than plan.traj holds used to overwrite times, row counts,
+    offsets and coefficients before the sampler refused -- a row-fed rollout then indexed past the row buffer."""
+    import torch
+    wps = _missions(500, 8)
+    plan = eng.plan(wps, 3.0, 0.01)
+    fleet = eng.fleet(plan, from_plan=False)
+    ref_fleet = eng.fleet(plan, from_plan=False)
+    keep = {k: getattr(plan, k).clone() for k in ("times", "seg_rows", "row_offsets", "coeffs", "traj", "first_yaw", "status")}
+    # a slower cruise needs more rows than the buffer holds
+    old_v, plan.velocity = plan.velocity, 1.5
+    eng.replan(plan)
+    assert eng.take_flags() == [0, 0, 1, 0]
+    for k, v in keep.items():
+        assert torch.equal(getattr(plan, k), v), k
+    plan.velocity = old_v
+    fleet.rollout(1500)
+    ref_fleet.rollout(1500)
+    assert torch.equal(fleet.state, ref_fleet.state)
+    # and a plan that fits again goes through (same waypoints, faster cruise: fewer rows)
+    plan.velocity = 3.5
+    eng.replan(plan)
+    assert eng.take_flags() == [0, 0, 0, 0]
+    fresh = eng.plan(wps, 3.5, 0.01)
+    n = fresh.total_rows
+    assert torch.equal(plan.row_offsets, fresh.row_offsets) and torch.equal(plan.traj[:n], fresh.traj)
+    assert torch.equal(plan.coeffs, fresh.coeffs) and torch.equal(plan.times, fresh.times)
+
+
+def test_replan_under_a_flying_fleet_rebuilds_the_carried_yaw_scan(eng):
+    """round-2 ADVICE (low): the yaw scan a plan-fed vehicle carries (state rows 26-29) belongs to the coefficients it was
+    built from.  After Engine.replan without Fleet.reset() the plan-fed fleet must see the NEW plan's yaw, like the row-fed
+    fleet that reads the new rows."""
+    import torch
+    wps = _missions(256, 6)
+    plan = eng.plan(wps, 3.0, 0.01)
+    fed, rows = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False)
+    fed.rollout(2000)
+    rows.rollout(2000)
+    assert torch.equal(fed.state[:26], rows.state[:26])
+    # same row counts (same leg lengths), other headings: mirror the missions in y about their start
+    w2 = torch.as_tensor(wps, device=eng.device).clone()
+    w2[:, :, 1] = 2 * w2[:, :1, 1] - w2[:, :, 1]
+    plan.waypoints.copy_(w2)
+    eng.replan(plan)
+    assert eng.take_flags() == [0, 0, 0, 0]
+    fed.rollout(1500)
+    rows.rollout(1500)
+    assert torch.equal(fed.state[:26], rows.state[:26]) and torch.equal(fed.istate, rows.istate)

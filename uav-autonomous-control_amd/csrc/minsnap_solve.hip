@@ -146,6 +146,47 @@ __global__ void __launch_bounds__(256) row_offsets_kernel(const int32_t *__restr
     if (i == B - 1) row_offsets[B] = inc;
 }
 
+// Per-mission row totals from per-segment row counts that exist already (a gathered plan): the tail of row_counts_kernel.
+template <bool RAGGED>
+__global__ void __launch_bounds__(256) seg_totals_kernel(const int32_t *__restrict__ seg_rows, int B, int m_uniform,
+                                                         int32_t *__restrict__ totals, int64_t *__restrict__ tile_sum,
+                                                         int32_t *__restrict__ flags, const int64_t *__restrict__ seg_offsets) {
+    __shared__ int64_t wsum[4];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = 0;
+    if (b < B) {
+        int m = m_uniform;
+        size_t seg0 = (size_t)b * m_uniform;
+        if (RAGGED) {
+            seg0 = (size_t)seg_offsets[b];
+            const int64_t mb = seg_offsets[b + 1] - seg_offsets[b];
+            if (mb < 1 || mb > m_uniform) atomicOr(&flags[0], 1);
+            m = (int)(mb < 1 ? 1 : (mb > m_uniform ? m_uniform : mb));
+        }
+        for (int s = 0; s < m; ++s) {
+            const int32_t r = seg_rows[seg0 + s];
+            total += r > 0 ? r : 0;
+        }
+        if (total > 2147483647LL) { atomicOr(&flags[3], 1); total = 0; }
+        totals[b] = (int32_t)total;
+    }
+    const int64_t inc = block_inclusive_scan_256(total, wsum);
+    if (threadIdx.x == 255) tile_sum[blockIdx.x] = inc;
+}
+
+__global__ void __launch_bounds__(256) plan_commit_kernel(const double *__restrict__ times_s, const int32_t *__restrict__ seg_rows_s,
+                                                          const int64_t *__restrict__ row_offsets_s, int B, size_t n_seg,
+                                                          int64_t capacity_rows, double *__restrict__ times,
+                                                          int32_t *__restrict__ seg_rows, int64_t *__restrict__ row_offsets) {
+    if (row_offsets_s[B] > capacity_rows) return;          // refused as a whole (the sampler raises flag 2)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_seg; i += stride) {
+        times[i] = times_s[i];
+        seg_rows[i] = seg_rows_s[i];
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= (size_t)B; i += stride) row_offsets[i] = row_offsets_s[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // Local (per segment) KKT contribution.  Local index l: 0..3 = (v,a,j,lambda) at the segment's start
 // knot, 4..7 = the same at its end knot.  ip[e] = T^-e.
@@ -337,20 +378,27 @@ __global__ void __launch_bounds__(64) minsnap_solve_kernel(const double *__restr
 
 }  // namespace
 
-int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
-                            double *times, int32_t *seg_rows, int64_t *row_offsets, const int64_t *seg_offsets) {
+// totals [B] i32 followed by the tile sums [ceil(B/256)] i64 (8-byte aligned offset): scratch of the row-offset scan
+static int ensure_totals(uavac_ctx *ctx, int B, int64_t **tiles) {
     const int n_tiles = (B + 255) / 256;
     if ((size_t)B > ctx->totals_cap) {
         if (ctx->d_totals) UAVAC_HIP(ctx, hipFree(ctx->d_totals));
         ctx->d_totals = nullptr;
         ctx->totals_cap = 0;
-        // totals [B] i32 followed by the tile sums [ceil(B/256)] i64 (8-byte aligned offset)
         const size_t bytes = (((size_t)B * 4 + 7) & ~(size_t)7) + (size_t)n_tiles * 8;
         UAVAC_HIP(ctx, hipMalloc(&ctx->d_totals, bytes));
         ctx->totals_cap = (size_t)B;
     }
-    int64_t *tiles = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ctx->d_totals) +
-                                                 (((size_t)ctx->totals_cap * 4 + 7) & ~(size_t)7));
+    *tiles = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ctx->d_totals) +
+                                         (((size_t)ctx->totals_cap * 4 + 7) & ~(size_t)7));
+    return UAVAC_OK;
+}
+
+int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
+                            double *times, int32_t *seg_rows, int64_t *row_offsets, const int64_t *seg_offsets) {
+    const int n_tiles = (B + 255) / 256;
+    int64_t *tiles = nullptr;
+    if (int rc = ensure_totals(ctx, B, &tiles)) return rc;
     if (seg_offsets)
         hipLaunchKernelGGL(row_counts_kernel<true>, dim3(n_tiles), dim3(256), 0, ctx->stream, wp, B, m, velocity, dt,
                            times, seg_rows, ctx->d_totals, tiles, ctx->d_flags, seg_offsets);
@@ -359,6 +407,37 @@ int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, doub
                            times, seg_rows, ctx->d_totals, tiles, ctx->d_flags, seg_offsets);
     hipLaunchKernelGGL(row_offsets_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles,
                        row_offsets);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
+// row_offsets of a plan whose per-segment row counts exist already (they arrived from another rank,
+// uavac_gather_plan_dev): the second half of uavac_launch_row_counts on its own.
+int uavac_launch_row_offsets(uavac_ctx *ctx, const int32_t *seg_rows, int B, int m, int64_t *row_offsets,
+                             const int64_t *seg_offsets) {
+    const int n_tiles = (B + 255) / 256;
+    int64_t *tiles = nullptr;
+    if (int rc = ensure_totals(ctx, B, &tiles)) return rc;
+    if (seg_offsets)
+        hipLaunchKernelGGL(seg_totals_kernel<true>, dim3(n_tiles), dim3(256), 0, ctx->stream, seg_rows, B, m, ctx->d_totals,
+                           tiles, ctx->d_flags, seg_offsets);
+    else
+        hipLaunchKernelGGL(seg_totals_kernel<false>, dim3(n_tiles), dim3(256), 0, ctx->stream, seg_rows, B, m, ctx->d_totals,
+                           tiles, ctx->d_flags, seg_offsets);
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles,
+                       row_offsets);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
+// uavac_minsnap_plan_dev computes times / row counts / offsets into ctx scratch first; this kernel moves them into the
+// caller's arrays only when the plan fits the caller's row buffer -- a refused plan leaves every output as it was.
+int uavac_launch_plan_commit(uavac_ctx *ctx, const double *times_s, const int32_t *seg_rows_s, const int64_t *row_offsets_s,
+                             int B, int m, int64_t capacity_rows, double *times, int32_t *seg_rows, int64_t *row_offsets) {
+    const size_t n = (size_t)B * m;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(plan_commit_kernel, dim3(grid), dim3(256), 0, ctx->stream, times_s, seg_rows_s, row_offsets_s, B, n,
+                       capacity_rows, times, seg_rows, row_offsets);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

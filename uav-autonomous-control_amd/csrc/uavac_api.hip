@@ -250,6 +250,7 @@ void uavac_destroy(uavac_ctx *ctx) {
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_totals) (void)hipFree(ctx->d_totals);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_plan) (void)hipFree(ctx->d_plan);
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (hipEvent_t e : ctx->pin_ev)
@@ -448,14 +449,44 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
     if (!std::isfinite(velocity) || !std::isfinite(dt)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite velocity or dt");
     if (!(velocity > 0.0) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity and dt must be > 0");
     if (traj_capacity_rows < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative capacity");
-    // the whole chain enqueued from here: nothing returns to the caller (or to an interpreter) between the launches
-    if (int rc = uavac_launch_row_counts(ctx, wp, B, m, velocity, dt, times, seg_rows, row_offsets)) return rc;
-    if (int rc = uavac_launch_solve_bt(ctx, wp, times, B, m, coeffs, status)) return rc;
+    // The whole chain enqueued from here: nothing returns to the caller (or to an interpreter) between the launches.
+    // Times, row counts and offsets go to ctx scratch first; whether the plan fits the caller's row buffer is only known on
+    // the device (row_offsets_s[B]), so every later stage reads that one word: the commit kernel copies the three arrays
+    // into the caller's only when it fits, the solver and the sampler do nothing when it does not (the sampler raises
+    // flag 2).  A refused plan leaves times, seg_rows, row_offsets, coeffs, rows and first_yaw exactly as they were.
+    const size_t nseg = (size_t)B * m;
+    const size_t o_rows = uavac_arena_size(nseg * 8), o_offs = o_rows + uavac_arena_size(nseg * 4);
+    const size_t need = o_offs + uavac_arena_size(((size_t)B + 1) * 8);
+    if (need > ctx->plan_cap) {
+        UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));          // nothing enqueued may still use the old block
+        if (ctx->d_plan) UAVAC_HIP(ctx, hipFree(ctx->d_plan));
+        ctx->d_plan = nullptr;
+        ctx->plan_cap = 0;
+        void *p = nullptr;
+        UAVAC_HIP(ctx, hipMalloc(&p, need));
+        ctx->d_plan = static_cast<char *>(p);
+        ctx->plan_cap = need;
+    }
+    double *times_s = reinterpret_cast<double *>(ctx->d_plan);
+    int32_t *seg_rows_s = reinterpret_cast<int32_t *>(ctx->d_plan + o_rows);
+    int64_t *row_offsets_s = reinterpret_cast<int64_t *>(ctx->d_plan + o_offs);
+    if (int rc = uavac_launch_row_counts(ctx, wp, B, m, velocity, dt, times_s, seg_rows_s, row_offsets_s)) return rc;
+    if (int rc = uavac_launch_plan_commit(ctx, times_s, seg_rows_s, row_offsets_s, B, m, traj_capacity_rows, times, seg_rows,
+                                          row_offsets)) return rc;
+    if (int rc = uavac_launch_solve_bt(ctx, wp, times_s, B, m, coeffs, status, nullptr, row_offsets_s + B, traj_capacity_rows))
+        return rc;
     SampleExtras x;
     x.yaw_dense = yaw;
     x.first_yaw = first_yaw;
     x.capacity_rows = traj_capacity_rows;         // the sampler refuses (flag 2) instead of overrunning the buffer
-    return uavac_launch_sample(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x);
+    return uavac_launch_sample(ctx, coeffs, seg_rows_s, row_offsets_s, B, m, dt, traj, x);
+}
+
+int uavac_minsnap_row_offsets_dev(uavac_ctx *ctx, const int32_t *seg_rows, int B, int m, int64_t *row_offsets) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_plan_args(ctx, seg_rows, B, m)) return rc;
+    if (!row_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "null row_offsets");
+    return uavac_launch_row_offsets(ctx, seg_rows, B, m, row_offsets);
 }
 
 int uavac_yaw_scan_dev(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B, double *yaws) {

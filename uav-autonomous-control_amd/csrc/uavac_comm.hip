@@ -12,6 +12,7 @@
 
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -62,6 +63,24 @@ int uavac_comm_init_rank(uavac_ctx *ctx, const char id[UAVAC_COMM_ID_BYTES], int
     if (!id || !nccl_comm) return uavac_fail(ctx, UAVAC_EINVAL, "null id or output pointer");
     if (world < 1 || rank < 0 || rank >= world) return uavac_fail(ctx, UAVAC_EINVAL, "need 0 <= rank < world");
     *nccl_comm = nullptr;
+    // This library is compiled against /opt/rocm's rccl.h and binds, at run time, whichever librccl.so.1 the process
+    // mapped first -- in a Python process that is the RCCL bundled with torch (2.26 against a 2.27 header on this image).
+    // Only entry points whose signatures have been stable since NCCL 2.10 are called (group, send / recv, all-gather,
+    // communicator set-up and queries) and the only structure that crosses is the 128-byte ncclUniqueId, so a different
+    // MINOR version is accepted; a different major version, or a runtime older than 2.10, is refused here instead of
+    // failing somewhere inside a collective.
+    {
+        int rt = 0;
+        UAVAC_NCCL(ctx, ncclGetVersion(&rt));
+        const int rt_major = rt >= 10000 ? rt / 10000 : rt / 1000;
+        const int rt_minor = rt >= 10000 ? (rt / 100) % 100 : (rt / 100) % 10;
+        if (rt_major != NCCL_MAJOR || rt_minor < 10) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "RCCL runtime version %d does not match the rccl.h this library was built with (%d)",
+                     rt, NCCL_VERSION_CODE);
+            return uavac_fail(ctx, UAVAC_ECOMM, msg);
+        }
+    }
     ncclUniqueId u;
     std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm = nullptr;
@@ -143,6 +162,69 @@ int uavac_gather_rows_dev(uavac_ctx *ctx, void *nccl_comm, const double *rows, i
     }
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;                    // enqueued on the ctx stream; uavac_comm_finish() synchronises and checks
+}
+
+int uavac_gather_plan_dev(uavac_ctx *ctx, void *nccl_comm, const double *coeffs, const double *times, const int32_t *seg_rows,
+                          int64_t n_segments, const int64_t *seg_counts, int root, double *coeffs_out, double *times_out,
+                          int32_t *seg_rows_out) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm || !seg_counts) return uavac_fail(ctx, UAVAC_EINVAL, "null communicator or counts");
+    if (n_segments < 0) return uavac_fail(ctx, UAVAC_EINVAL, "n_segments must be >= 0");
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    int world = 0, rank = 0;
+    if (int rc = comm_shape(ctx, comm, &world, &rank)) return rc;
+    if (root < 0 || root >= world) return uavac_fail(ctx, UAVAC_EINVAL, "root out of range");
+    for (int r = 0; r < world; ++r)
+        if (seg_counts[r] < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
+    if (seg_counts[rank] != n_segments) return uavac_fail(ctx, UAVAC_EINVAL, "seg_counts[rank] != n_segments");
+    if (n_segments > 0 && (!coeffs || !seg_rows)) return uavac_fail(ctx, UAVAC_EINVAL, "null coeffs or seg_rows");
+    const size_t n = (size_t)n_segments;
+    if (rank == root) {
+        std::vector<size_t> off((size_t)world + 1, 0);
+        for (int r = 0; r < world; ++r) off[r + 1] = off[r] + (size_t)seg_counts[r];
+        if (off[world] > 0 && (!coeffs_out || !seg_rows_out)) return uavac_fail(ctx, UAVAC_EINVAL, "null output on the root");
+        if (n > 0 && (times_out != nullptr) != (times != nullptr))
+            return uavac_fail(ctx, UAVAC_EINVAL, "times and times_out go together (on every rank, or on none)");
+        const size_t o = off[rank];
+        if (n > 0) {                                                // the root's own block: device-to-device copies
+            if (coeffs_out + o * 24 != coeffs)
+                UAVAC_HIP(ctx, hipMemcpyAsync(coeffs_out + o * 24, coeffs, n * 24 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (times_out && times && times_out + o != times)
+                UAVAC_HIP(ctx, hipMemcpyAsync(times_out + o, times, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (seg_rows_out + o != seg_rows)
+                UAVAC_HIP(ctx, hipMemcpyAsync(seg_rows_out + o, seg_rows, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        // one grouped launch for all peers and all three arrays: the receives of different peers run concurrently, one per
+        // direct xGMI link into the root
+        UAVAC_NCCL(ctx, ncclGroupStart());
+        ncclResult_t res = ncclSuccess;
+        for (int r = 0; r < world && res == ncclSuccess; ++r) {
+            if (r == root || seg_counts[r] == 0) continue;
+            const size_t c = (size_t)seg_counts[r];
+            res = ncclRecv(coeffs_out + off[r] * 24, c * 24, ncclDouble, r, comm, ctx->stream);
+            if (res == ncclSuccess && times_out) res = ncclRecv(times_out + off[r], c, ncclDouble, r, comm, ctx->stream);
+            if (res == ncclSuccess) res = ncclRecv(seg_rows_out + off[r], c, ncclInt32, r, comm, ctx->stream);
+        }
+        if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclRecv", res); }
+        UAVAC_NCCL(ctx, ncclGroupEnd());
+    } else if (n > 0) {
+        UAVAC_NCCL(ctx, ncclGroupStart());
+        ncclResult_t res = ncclSend(coeffs, n * 24, ncclDouble, root, comm, ctx->stream);
+        if (res == ncclSuccess && times) res = ncclSend(times, n, ncclDouble, root, comm, ctx->stream);
+        if (res == ncclSuccess) res = ncclSend(seg_rows, n, ncclInt32, root, comm, ctx->stream);
+        if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclSend", res); }
+        UAVAC_NCCL(ctx, ncclGroupEnd());
+    }
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;                    // enqueued on the ctx stream; uavac_comm_finish() synchronises and checks
+}
+
+int uavac_comm_versions(int *built_with, int *runtime) {
+    if (built_with) *built_with = NCCL_VERSION_CODE;
+    int rt = 0;
+    if (ncclGetVersion(&rt) != ncclSuccess) return UAVAC_ECOMM;
+    if (runtime) *runtime = rt;
+    return UAVAC_OK;
 }
 
 int uavac_comm_finish(uavac_ctx *ctx, void *nccl_comm) {

@@ -18,6 +18,8 @@ struct uavac_ctx {
     size_t totals_cap = 0;
     double *d_ws = nullptr;          // block-Thomas workspace [m-1][28][B]
     size_t ws_cap = 0;               // in doubles
+    char *d_plan = nullptr;          // uavac_minsnap_plan_dev: times / seg_rows / row_offsets before they are committed
+    size_t plan_cap = 0;             // in bytes
     // Device scratch of the host-pointer twins and small internal temporaries: one arena, grown on demand and kept,
     // handed out by bump allocation inside one entry point (uavac_arena_reserve, then uavac_arena_take).  Reuse across
     // calls is ordered by the ctx stream.
@@ -133,8 +135,16 @@ int uavac_check_vehicle(uavac_ctx *ctx, const uavac_vehicle *V);
 // m = the batch's maximum); waypoints, times, row counts, coefficients and hit flags lie back to back
 int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                             double *times, int32_t *seg_rows, int64_t *row_offsets, const int64_t *seg_offsets = nullptr);
+// guard_rows (device, may be NULL): the launch does nothing when *guard_rows > guard_capacity (a refused planning chain)
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
-                          int32_t *status, const int64_t *seg_offsets = nullptr);
+                          int32_t *status, const int64_t *seg_offsets = nullptr, const int64_t *guard_rows = nullptr,
+                          int64_t guard_capacity = 0);
+// row_offsets [B+1] from per-segment row counts that exist already (minsnap_solve.hip)
+int uavac_launch_row_offsets(uavac_ctx *ctx, const int32_t *seg_rows, int B, int m, int64_t *row_offsets,
+                             const int64_t *seg_offsets = nullptr);
+// times / seg_rows / row_offsets from scratch into the caller's arrays unless row_offsets_s[B] > capacity_rows
+int uavac_launch_plan_commit(uavac_ctx *ctx, const double *times_s, const int32_t *seg_rows_s, const int64_t *row_offsets_s,
+                             int B, int m, int64_t capacity_rows, double *times, int32_t *seg_rows, int64_t *row_offsets);
 int uavac_launch_solve(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                        int32_t *status);
 // Optional outputs / inputs of the sampler (minsnap_sample.hip)

@@ -20,7 +20,7 @@ OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM = 0, -1, -2, -3, -4, -5, 
 COMM_ID_BYTES = 128
 MAX_SEGMENTS = 64
 TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 30, 4, 12
-VERSION = 200
+VERSION = 300
 GROUND_IN_CONTACT, GROUND_TAKEN_OFF, GROUND_HIT_AFTER_TAKEOFF = 1, 2, 4       # istate row 3 (include/uavac.h)
 
 
@@ -76,6 +76,7 @@ _SIGNATURES = {
     "uavac_minsnap_sample_derivs_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]),
     "uavac_minsnap_plan_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P, _P,
                                           C.c_int64, _P, _P]),
+    "uavac_minsnap_row_offsets_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "uavac_minsnap_plan_ragged": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, C.c_int64]),
     "uavac_minsnap_row_counts_ragged_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
     "uavac_minsnap_solve_ragged_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
@@ -127,6 +128,8 @@ _SIGNATURES = {
     "uavac_comm_shape": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "uavac_gather_counts": (C.c_int, [_P, _P, C.c_int64, _P]),
     "uavac_gather_rows_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, C.c_int, _P]),
+    "uavac_gather_plan_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, _P, _P, _P]),
+    "uavac_comm_versions": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "uavac_comm_finish": (C.c_int, [_P, _P]),
     "uavac_comm_loopback_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
 }

@@ -46,6 +46,8 @@ class Plan:
     yaw: "object" = None     # (N,) f64 or None: the yaw column on its own (== traj[:, 9]); one way to feed the plan-fed rollout
     first_yaw: "object" = None   # (B,) f64: heading of each mission's first row that has one; lets the rollout scan the yaw itself
     placement_ms: "object" = None    # sampler times of the candidate row buffers when plan(..., placement_trials > 1) chose one
+    epoch: int = 0                   # bumped whenever the plan is re-solved / re-sampled in place (Engine.replan / solve / sample):
+                                     # an attached Fleet then rebuilds the yaw scan it carries instead of trusting a stale one
 
     def mission(self, b: int) -> np.ndarray:
         """Rows of mission b as a fresh host array (N_b, 11) -- the reference's `full_trajectory`."""
@@ -202,12 +204,13 @@ class Engine:
         plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw, first_yaw)
         self.sample(plan)
         if int(placement_trials) > 1 and total > 0:
-            self._place_rows(plan, int(placement_trials))
+            self.place_rows(plan, int(placement_trials))
         if strict:
             self.check(plan)
         return plan
 
-    def _place_rows(self, plan: Plan, trials: int):
+    def place_rows(self, plan: Plan, trials: int):
+        """Optional: choose `plan.traj` among up to `trials` candidate allocations by timing the sampler on each (see `plan`)."""
         torch = self._torch
 
         def timed(buf):
@@ -239,11 +242,42 @@ class Engine:
         """The whole chain again into plan's buffers -- times + row counts, offsets, solve, sampler (+ yaw column) --
         enqueued by ONE call into the C ABI (`uavac_minsnap_plan_dev`): no allocation, no sync, no Python between
         the four launches.  The buffers keep their size: a plan that would need more rows than `plan.traj` holds is
-        refused on the device (flag 2, see `take_flags`)."""
+        refused on the device AS A WHOLE (flag 2, see `take_flags`): every array of the plan keeps what it held, so the
+        previous plan stays consistent and flyable."""
         self._bind_stream()
         self.ctx.call("uavac_minsnap_plan_dev", _ptr(plan.waypoints), plan.B, plan.m, plan.velocity, plan.dt,
                       _ptr(plan.times), _ptr(plan.seg_rows), _ptr(plan.row_offsets), _ptr(plan.coeffs), _ptr(plan.status),
                       _ptr(plan.traj), int(plan.traj.shape[0]), _ptr(plan.yaw), _ptr(plan.first_yaw))
+        plan.epoch += 1
+
+    def plan_from_parts(self, coeffs, times, seg_rows, m: int, velocity: float, dt: float, total_rows: int = None,
+                        traj=None) -> Plan:
+        """A Plan from its solved parts -- coefficients (B, 8m, 3), durations (B, m) or None, rows per spline (B, m) -- e.g.
+        the peers' plans after `RcclComm.gather_plan`: row offsets from the row counts (`uavac_minsnap_row_offsets_dev`),
+        then the sampler writes the rows (and the first headings).  The rows are a deterministic function of coefficients,
+        row counts and dt: bit-identical to the rows of the plan the parts came from.  `total_rows` (when the caller knows
+        it) avoids the one host synchronisation that sizes the row buffer; `traj`: a preallocated (>= total, 11) buffer."""
+        torch = self._torch
+        co = self._dev(coeffs, torch.float64).reshape(-1, 8 * int(m), 3)
+        sr = self._dev(seg_rows, torch.int32).reshape(-1, int(m))
+        B = int(co.shape[0])
+        if sr.shape[0] != B or B < 1:
+            raise ValueError("coeffs and seg_rows disagree on the number of missions")
+        tm = None if times is None else self._dev(times, torch.float64).reshape(B, int(m))
+        kw = dict(device=self.device)
+        row_offsets = torch.empty((B + 1,), dtype=torch.int64, **kw)
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_row_offsets_dev", _ptr(sr), B, int(m), _ptr(row_offsets))
+        total = int(row_offsets[-1].item()) if total_rows is None else int(total_rows)
+        if traj is None:
+            traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
+        elif traj.shape[0] < total or traj.dtype != torch.float64 or not traj.is_contiguous():
+            raise ValueError("traj must be a contiguous float64 tensor with at least total_rows rows")
+        first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
+        status = torch.zeros((B,), dtype=torch.int32, **kw)
+        plan = Plan(B, int(m), float(velocity), float(dt), None, tm, sr, row_offsets, co, status, traj[:total], total, None, first_yaw)
+        self.sample(plan)
+        return plan
 
     def take_flags(self):
         """Synchronise and return-and-clear the sticky device-side flags of the `_dev` planning entry points:
@@ -439,6 +473,7 @@ class Engine:
                       _ptr(plan.times), _ptr(plan.seg_rows), _ptr(plan.row_offsets))
         self.ctx.call("uavac_minsnap_solve_dev", _ptr(plan.waypoints), _ptr(plan.times), plan.B, plan.m,
                       _ptr(plan.coeffs), _ptr(plan.status))
+        plan.epoch += 1
 
     def sample(self, plan: Plan):
         """Re-run the sampler + yaw scan into plan.traj (and plan.yaw / plan.first_yaw when the plan has them); no
@@ -574,8 +609,11 @@ class Fleet:
             self._positions = engine._dev(positions, torch.float64)
         elif hasattr(plan, "start_positions"):
             self._positions = plan.start_positions.contiguous()
-        else:
+        elif getattr(plan, "waypoints", None) is not None:
             self._positions = plan.waypoints[:, 0, :].contiguous()
+        else:                                    # a plan assembled from gathered parts: c0 of the first spline IS the first waypoint
+            self._positions = plan.coeffs[:, 0, :].contiguous()
+        self._plan_epoch = getattr(plan, "epoch", 0)
         self.reset()
 
     def reset(self):
@@ -584,6 +622,7 @@ class Fleet:
         e._bind_stream()
         e.ctx.call("uavac_state_init_dev", C.byref(self.vehicle), _ptr(self._positions), self.B,
                    int(self._hover), _ptr(self.state), _ptr(self.istate))
+        self._plan_epoch = getattr(self.plan, "epoch", 0)        # the carried yaw scan starts afresh
 
     def rollout(self, K: int, state_log=None, cmd_log=None, aabbs=None):
         """K fused ticks.  state_log / cmd_log: None, True (allocate) or a preallocated tensor.
@@ -604,6 +643,12 @@ class Fleet:
             n_obs = int(ab.shape[0])
         e._bind_stream()
         p = self.plan
+        if self.from_plan and getattr(p, "epoch", 0) != self._plan_epoch:
+            # the plan was re-solved under a flying fleet (Engine.replan / solve without reset()): the yaw scan the vehicles
+            # carry (state rows 26-29) belongs to the old coefficients.  Row -1 matches no cursor, so the kernel rebuilds
+            # the scan from the mission's first row with the new ones -- what reading a dense yaw column would give.
+            self.state[26].fill_(-1.0)
+            self._plan_epoch = p.epoch
         if self.from_plan and hasattr(p, "seg_offsets"):
             if self.yaw_from == "column":
                 raise ValueError("a ragged batch has no dense yaw column: yaw_from='scan'")
@@ -729,8 +774,47 @@ class RcclComm:
                        (C.c_int64 * self.world)(*counts), int(dst), _ptr(out))
         return (stream, out, counts, rows)
 
+    def gather_plan(self, plan: Plan, dst: int = 0, traj=None):
+        """The final gather as a gather of the PLAN: every rank sends the coefficients, durations and per-spline row
+        counts of its missions (204 B per spline; ~10 KB of rows per spline stay where they are), and `dst` re-samples
+        them with the very kernel the peers ran -> (Plan of all missions on dst | None, row counts per rank).
+        `gathered.traj` equals what `gather_rows(plan.traj)` delivers, bit for bit.  Synchronous."""
+        return self.gather_finish(self.gather_plan_begin(plan, dst, traj=traj))
+
+    def gather_plan_begin(self, plan: Plan, dst: int = 0, stream=None, traj=None):
+        """Enqueue `gather_plan` and return at once (`stream`, ticket: as for `gather_rows_begin`; the root's re-sampling
+        is enqueued on that stream too, behind the receives).  `traj`: a preallocated row buffer for the root."""
+        e, torch = self.engine, self.engine._torch
+        if not hasattr(plan, "m") or getattr(plan, "coeffs", None) is None or not plan.coeffs.is_cuda:
+            raise ValueError("gather_plan takes a device-resident Plan (one segment count per batch)")
+        m = int(plan.m)
+        here = torch.cuda.current_stream(e.device)
+        stream = here if stream is None else stream
+        if stream is not here:
+            stream.wait_stream(here)
+        with torch.cuda.stream(stream):
+            seg_counts = self.counts(plan.B * m)             # two tiny synchronous all-gathers on that stream
+            row_counts = self.counts(plan.total_rows)
+            if any(c % m for c in seg_counts):
+                raise ValueError(f"every rank must plan with the same segment count (m = {m} here)")
+            gathered = keep = None
+            S = sum(seg_counts)
+            co = tm = sr = None
+            if self.rank == dst:
+                kw = dict(device=e.device)
+                co = torch.empty((S // m, 8 * m, 3), dtype=torch.float64, **kw)
+                tm = torch.empty((S // m, m), dtype=torch.float64, **kw) if plan.times is not None else None
+                sr = torch.empty((S // m, m), dtype=torch.int32, **kw)
+            e._bind_stream()
+            e.ctx.call("uavac_gather_plan_dev", self._h, _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows), plan.B * m,
+                       (C.c_int64 * self.world)(*seg_counts), int(dst), _ptr(co), _ptr(tm), _ptr(sr))
+            if self.rank == dst:
+                gathered = e.plan_from_parts(co, tm, sr, m, plan.velocity, plan.dt, total_rows=sum(row_counts), traj=traj)
+            keep = plan
+        return (stream, gathered, row_counts, keep)
+
     def gather_finish(self, ticket):
-        """Wait for a gather started with `gather_rows_begin` -> (all_rows on dst | None, counts)."""
+        """Wait for a gather started with `gather_rows_begin` / `gather_plan_begin` -> (result on dst | None, counts)."""
         e, torch = self.engine, self.engine._torch
         stream, out, counts, _rows = ticket
         with torch.cuda.stream(stream):
@@ -762,6 +846,37 @@ class RcclComm:
             self.close()
         except Exception:                # pragma: no cover - interpreter shutdown
             pass
+
+
+def gather_plan(plan, dst: int = 0, group=None, comm: "RcclComm" = None, engine: "Engine" = None):
+    """`RcclComm.gather_plan` with the host rehearsal path beside it (like `gather_rows`).
+
+    A device-resident Plan + `comm`: RCCL behind the C ABI.  Otherwise the plan's parts travel as HOST tensors through
+    `torch.distributed` point-to-point messages (gloo) in the same layout -- the rehearsal path of the multi-process CPU
+    tests and of `UAVAC_BENCH_REHEARSAL`; on dst the result is a Plan re-sampled on `engine`'s GPU when one is given, else
+    the gathered parts `{"coeffs", "times", "seg_rows", "m"}` as host tensors.  Returns (result | None, row counts)."""
+    torch = _torch()
+    if comm is not None and getattr(plan.coeffs, "is_cuda", False):
+        return comm.gather_plan(plan, dst)
+    import torch.distributed as dist
+    m = int(plan.m)
+    host = lambda t, dt_: torch.as_tensor(np.asarray(t.cpu() if hasattr(t, "cpu") else t)).to(dt_).contiguous()   # noqa: E731
+    co, _ = gather_rows(host(plan.coeffs, torch.float64).reshape(-1, 24), dst, group)
+    tm = None
+    if plan.times is not None:
+        tm, _ = gather_rows(host(plan.times, torch.float64).reshape(-1, 1), dst, group)
+    sr, _ = gather_rows(host(plan.seg_rows, torch.int32).reshape(-1, 1), dst, group)
+    n = torch.tensor([int(plan.total_rows)], dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    if dist.get_rank(group) != dst:
+        return None, counts
+    if engine is not None:
+        return engine.plan_from_parts(co.reshape(-1, 8 * m, 3), None if tm is None else tm.reshape(-1, m), sr.reshape(-1, m), m,
+                                      plan.velocity, plan.dt, total_rows=sum(counts)), counts
+    return {"coeffs": co.reshape(-1, 8 * m, 3), "times": None if tm is None else tm.reshape(-1, m), "seg_rows": sr.reshape(-1, m),
+            "m": m}, counts
 
 
 def gather_rows(rows, dst: int = 0, group=None, max_message_bytes: int = 1 << 30, comm: "RcclComm" = None):
