@@ -480,6 +480,7 @@ def main():
 
         step4()
         c4_compute = timed(step4, 3)
+        c4_fly = timed(fly4, 3)                              # the 5 000 ticks alone (planning is 12 % of this job)
         # what re-sampling this rank's rows from its plan costs (at N = 1: all 262 144 missions = what the root of the plan
         # gather pays at any N, on top of its own share of the flight)
         a, b = ev(), ev()
@@ -494,6 +495,7 @@ def main():
               "batch_total": C4_TOTAL, "batch_per_gpu": B4, "segments": C4_SEGMENTS, "ticks": C4_TICKS,
               "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
               "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel(),
+              "rollout_ms": c4_fly * 1e3, "steps_per_s_rollout_only": C4_TOTAL * C4_TICKS / c4_fly,
               "resample_rank0_rows_ms": a.elapsed_time(b) / 3,
               "plan_bytes_rank0": int(plan4.B * C4_SEGMENTS * 204), "row_bytes_rank0": int(plan4.total_rows * 88)}
         if rank == 0:

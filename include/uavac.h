@@ -107,8 +107,14 @@ const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
  * precede a rollout launch that writes a log by an empty kernel of the same workgroup shape (one
  * compute + one store wave), which makes the hardware place one wave of each kind on every SIMD
  * whatever ran before; 0 = do not.  "yaw_group": 1, 4, 8 (default) or 16 = how
- * many 64-row chunks of the sampler's dense yaw column are written together.  Defaults from the
- * environment (UAVAC_ROLLOUT_ALIGN, UAVAC_YAW_GROUP) at uavac_create. */
+ * many 64-row chunks of the sampler's dense yaw column are written together.  "late_handover": -1
+ * (default: chosen per launch), 0, 1 = when the compute wave hands a tick's log values to the store
+ * wave.  "lds_pad": extra LDS bytes per rollout workgroup (caps the workgroups a CU takes; 0).
+ * Defaults from the environment (UAVAC_ROLLOUT_ALIGN, UAVAC_YAW_GROUP) at uavac_create.
+ * ONE option is not a tuning knob but part of the log layout: "log_pitch" = P doubles per log row,
+ * 0 (default) = B.  With P >= B the rollouts write state_log [K][13][P] and cmd_log [K][12][P]
+ * (columns B .. P-1 are never touched).  Rows of a multiple of 16 doubles start on 128-byte lines
+ * whatever B is: B = 65 534 with P = 65 536 streams like B = 65 536, with P = B at half that rate. */
 int uavac_set_option(uavac_ctx *ctx, const char *name, int value);
 /* The _dev planning entry points report data-dependent failures through sticky device-side flags
  * instead of synchronising: flags[0] non-finite segment duration, flags[1] singular knot system,
@@ -262,8 +268,9 @@ int uavac_state_init_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *p
  * cmd_log [K][12][B] (thrust_cmd, pqr_cmd, omega_command, omega after the controller part
  * of every tick) or NULL; aabbs [n_obs][6] = xmin xmax ymin ymax zmin zmax (inclusive test of
  * minimum_snap.py:327-357, evaluated on the position after every tick) or NULL.
- * Any B is accepted; the logs stream at full rate when B is a multiple of 16 (rows of B doubles
- * then start on 128-byte lines). */
+ * Any B is accepted; the logs stream at full rate when their rows start on 128-byte lines: B a
+ * multiple of 16, or uavac_set_option(ctx, "log_pitch", P) with P >= B a multiple of 16 -- the logs
+ * are then [K][13][P] and [K][12][P]. */
 int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const double *traj,
                               const int64_t *row_offsets, double *state, int32_t *istate, int B,
                               int K, double *state_log, double *cmd_log, const double *aabbs,

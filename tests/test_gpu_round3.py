@@ -159,3 +159,76 @@ def test_replan_under_a_flying_fleet_rebuilds_the_carried_yaw_scan(eng):
     fed.rollout(1500)
     rows.rollout(1500)
     assert torch.equal(fed.state[:26], rows.state[:26]) and torch.equal(fed.istate, rows.istate)
+
+
+@pytest.mark.parametrize("B", [1000, 4097, 70001])
+def test_pitched_logs_equal_dense_logs_and_leave_the_padding_alone(eng, B):
+    """round-2 VERDICT 4a: log rows `pitch` doubles apart (uavac_set_option "log_pitch"; Fleet picks a multiple of 16).
+    Same values as the dense [K][13][B] layout, padding columns never written.  B = 70 001 also walks the persistent-tile
+    loop (more 64-UAV tiles than SIMDs) with a ragged last tile."""
+    import torch
+    plan = eng.plan(_missions(B, 3), 3.0, 0.01)
+    K = 130
+    f0, f1 = eng.fleet(plan, from_plan=False), eng.fleet(plan, from_plan=False)
+    dense_s = torch.empty((K, 13, B), dtype=torch.float64, device=eng.device)
+    dense_c = torch.empty((K, 12, B), dtype=torch.float64, device=eng.device)
+    f0.rollout(K, state_log=dense_s, cmd_log=dense_c)
+    P = -(-B // 16) * 16 + 48
+    ps = torch.full((K, 13, P), -5.0, dtype=torch.float64, device=eng.device)
+    pc = torch.full((K, 12, P), -5.0, dtype=torch.float64, device=eng.device)
+    s_view, c_view = f1.rollout(K, state_log=ps, cmd_log=pc)
+    assert s_view.data_ptr() == ps.data_ptr()
+    assert torch.equal(ps[:, :, :B], dense_s) and torch.equal(pc[:, :, :B], dense_c)
+    assert bool((ps[:, :, B:] == -5.0).all()) and bool((pc[:, :, B:] == -5.0).all())
+    assert torch.equal(f0.state, f1.state) and torch.equal(f0.istate, f1.istate)
+    # logs allocated by the fleet come back as (K, rows, B) views of pitched buffers
+    f2 = eng.fleet(plan, from_plan=False)
+    s2, c2 = f2.rollout(K, state_log=True, cmd_log=True)
+    assert s2.shape == (K, 13, B) and s2.stride(1) % 16 == 0
+    assert torch.equal(s2, dense_s) and torch.equal(c2, dense_c)
+    # a pitch below B is refused
+    eng.ctx.set_option("log_pitch", B - 1)
+    try:
+        with pytest.raises(Exception):
+            f2._launch_rollout(1, dense_s, None, None)
+    finally:
+        eng.ctx.set_option("log_pitch", 0)
+
+
+def test_placeholder_wave_between_compute_and_store_wave_changes_no_bit(eng):
+    """Option "idle_waves": a third wave between the compute and the store wave of every workgroup that ends at once, so that
+    two workgroups on a CU get a SIMD each for all four of their working waves (the launcher's choice for 16 385 .. 32 768
+    UAVs).  The workgroup's barriers go on without the wave that has ended; state log, command log, collision flags and
+    final state equal those of the two-wave launch, for both feeds."""
+    import torch
+    B, K = 3000, 400
+    plan = eng.plan(_missions(B, 8), 3.0, 0.01)
+    boxes = np.array([[3.7, 4.3, 4, 10, -3.4, -2.8], [10.7, 11.3, 4, 10, -2.2, 0], [13.3, 14.7, 6.3, 7.7, -6, 0],
+                      [20.2, 20.8, 4, 10, -3.3, -2.7], [0, 30, 0, 20, -3.2, -3.1], [5, 6, 5, 6, -4, -2], [7, 9, 1, 3, -5, -1],
+                      [1, 2, 1, 2, -4, -2], [11, 12, 3, 9, -4, -2], [15, 16, 2, 4, -4, -2]])
+    for feed in (False, True):
+        for n_obs, logs in ((0, (True, False)), (10, (True, True)), (4, (False, True)), (8, (True, False)), (3, (False, False))):
+            out = []
+            for idle in (0, 1):
+                eng.ctx.set_option("idle_waves", idle)
+                try:
+                    f = eng.fleet(plan, from_plan=feed)
+                    s, c = f.rollout(K, state_log=logs[0] or None, cmd_log=logs[1] or None,
+                                     aabbs=boxes[:n_obs] if n_obs else None)
+                    torch.cuda.synchronize()
+                finally:
+                    eng.ctx.set_option("idle_waves", -1)
+                out.append((s, c, f.state.clone(), f.istate.clone()))
+            for a, b in zip(*out):
+                assert (a is None and b is None) or torch.equal(a, b), (feed, n_obs, logs)
+            if n_obs:
+                assert int(out[0][3][2].sum()) > 0             # somebody did fly into a cuboid
+    # the launcher's own choice at a half-full chip equals the explicit two-wave launch too
+    plan = eng.plan(_missions(20000, 2), 3.0, 0.01)
+    logs = []
+    for idle in (0, -1):
+        eng.ctx.set_option("idle_waves", idle)
+        f = eng.fleet(plan, from_plan=False)
+        logs.append(f.rollout(60, state_log=True)[0])
+    eng.ctx.set_option("idle_waves", -1)
+    assert torch.equal(logs[0], logs[1])

@@ -20,7 +20,7 @@ for i,(a,op,args,c) in enumerate(ins):
         if mm and base+int(mm.group(1),16) in addr: br.append((i,addr[base+int(mm.group(1),16)],op))
 bars=[i for i,x in enumerate(ins) if x[1]=='s_barrier']
 loops=[(i-t,t,i) for i,t,op in br if t<=i and (not bars or any(t<=b<=i for b in bars))]
-_,lo,hi=max(loops)
+big=[l for l in loops if l[0]>=400]; _,lo,hi=min(big) if big else max(loops)      # the tick loop: the smallest loop around a barrier that is long enough to be it (the persistent-tile loop around it is larger)
 fwd=[(t-i,i,t) for i,t,op in br if lo<=i<t<=hi and op=='s_cbranch_execz']
 _,olo,ohi=max(fwd)
 inner=[ins[i] for i in range(lo,hi+1) if not (olo<i<ohi)]

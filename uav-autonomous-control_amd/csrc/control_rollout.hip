@@ -113,11 +113,12 @@ constexpr int poly_tile_doubles(bool yawscan) { return (24 + (yawscan ? 0 : 16))
 // first heading take P.first_yaw[b].  A cursor that does not match the carried scan (a caller moved it, another kernel
 // advanced it) is caught at launch and the scan is rebuilt from row 0.  No yaw bytes are read or written at all.
 template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN>
-__global__ void __launch_bounds__(64 * CW + ((LOG_STATE || LOG_CMD || AABB) ? 64 * SW : 0))
+__global__ void __launch_bounds__((LOG_STATE || LOG_CMD || AABB) ? 64 * CW + 128 : 64 * CW)       // compute [+ placeholder] + store
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
                        double *__restrict__ state_log, double *__restrict__ cmd_log,
-                       const double *__restrict__ aabbs, int n_obs, int col_base, const PlanRef P, int late_handover) {
+                       const double *__restrict__ aabbs, int n_obs, int n_tiles, size_t log_pitch, const PlanRef P,
+                       int late_handover, int n_idle) {
     // WATCH: obstacles but no log at all -- the second wave exists all the same and only WATCHES: it takes the three
     // position values of every tick through the slab and tests them against obstacle bounds held in its registers.  In the
     // compute wave the same test cost 0.4 us per tick for four obstacles (a scalar-cache round trip per obstacle on the
@@ -129,27 +130,43 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     constexpr int CMD0 = LOG_STATE ? 13 : 0;                           // first command row in a slab
     extern __shared__ double slab[];                                   // [2][NR][NU]
     const size_t sB = (size_t)B;
-    // XCD-aware tile order (uavac_internal.h): every XCD owns one contiguous eighth of the launch's columns.  For this
-    // kernel it is neutral (measured 1.64 ms per 1 000 ticks either way: the kernel is bound by total HBM traffic at
-    // ~4.9 TB/s, not by the store stream alone); a store-only kernel with the same log pattern gains 16 %.
-    const int col0 = col_base + xcd_contiguous(blockIdx.x, gridDim.x) * NU;     // the launch covers [col_base, col_base + grid NU)
+    // The logs are [K][13 | 12][log_pitch]: rows of log_pitch >= B doubles.  With log_pitch a multiple of 16 every row starts
+    // on a 128-byte line whatever B is (B = 65 534 with pitch B ran at half the rate of 65 536: every 512-byte wave store
+    // straddled two partially written lines).
+    const size_t sP = log_pitch;
+    // PERSISTENT TILES.  A tile = NU consecutive UAVs flown for the launch's K ticks.  The launch has at most one workgroup
+    // per SIMD (the launcher caps the grid when a log is written); a batch with more tiles than that is walked by the same
+    // workgroups, pass after pass, each workgroup moving on to its next tile as soon as its own K ticks are done -- no launch
+    // boundary between the passes at which every SIMD would wait for the slowest one (round 2 issued one launch per 65 536
+    // columns: 262 144 UAVs ran at 45 G steps/s against 52 G at 65 536).  Results do not depend on the split (tested).
+    // XCD-aware tile order inside a pass (uavac_internal.h): every XCD owns one contiguous span of the pass's columns.
+    const int grid = (int)gridDim.x;
+    int kk = 0;                                    // ticks of earlier tiles: the slab ping-pong keeps alternating across tiles
+
+    // PLACEHOLDER WAVES.  A CU deals the waves of a workgroup round its SIMDs in the order s, s+2, s+1, s+3 and starts the
+    // NEXT workgroup one position later in that sequence (tools/census_detail.py).  Four [compute, store] workgroups on a CU
+    // therefore end up one compute + one store wave per SIMD -- but TWO of them (B <= 32 768) put the second compute wave on
+    // the SIMD of the first store wave and leave one SIMD idle.  With a wave between the two that ends at once --
+    // [compute, placeholder, store] -- two workgroups occupy all four SIMDs with one wave each.  A wave that has ended no
+    // longer takes part in the workgroup's barriers.
+    if (LOGGING && n_idle > 0 && threadIdx.x >= NU && threadIdx.x < NU + 64 * n_idle) return;
 
     if (LOGGING && threadIdx.x >= NU) {
         // ------------------------------------------------------------------------------ store wave(s)
-        // SW store waves share the workgroup's NU columns: store wave w covers columns [w, w + 1) * QPL * 64, QPL
-        // 64-column blocks of it per lane.
-        constexpr int QPL = CW / SW;
-        const int lane = (threadIdx.x & 63) + ((threadIdx.x - NU) >> 6) * (QPL * 64);
+        static_assert(CW == 1 && SW == 1, "one compute + one store wave per 64-UAV tile");
+        constexpr int QPL = 1;
+        // (Measured and not kept, all bit-identical, tools/rollout_shapes.py, profiles/r03_rollout_shapes_*.jsonl: two or three
+        // store waves per tile sharing a tick's 13 log rows -- 0.93 -> 0.92 ms per 1 000 ticks at B = 32 768, slower from
+        // 40 960 up; two compute + two store waves per 128-UAV workgroup, which a CU deals one per SIMD -- slower at every
+        // size, 0.87 against 0.77 ms even at B = 16 384: the per-tick barrier then couples two compute waves.)
+        const int lane = threadIdx.x & 63;
         __builtin_amdgcn_s_setprio(3);            // few instructions, all on the critical store stream: issue first
-        const bool full = col0 + NU <= B;          // every column of this workgroup exists: no per-store mask
         const unsigned lane_bytes = (unsigned)lane * 8u;
         // With a state log the per-tick obstacle test runs HERE, on the positions this wave is about to store, after
         // its stores have been issued: the compute wave's tick stays as short as without obstacles (the two stages
         // couple through one barrier per tick; lengthening the compute stage to the length of the store stage cost
         // 40 % at config 5), and the comparisons fill time in which this wave would wait for the store path anyway.
         constexpr bool AABB_HERE = AABB && (LOG_STATE || WATCH) && QPL == 1;
-        const bool mine = col0 + lane < B;
-        int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
         // The first kBoxRegs obstacles live in vector registers for the whole launch (this wave has ~200 to spare: the
         // kernel's allocation is sized by the compute wave).  Fetched through uniform addresses they would be scalar
         // loads -- one s_load + s_waitcnt round trip per obstacle per TICK on the critical store stream.
@@ -169,34 +186,37 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 #pragma unroll
                 for (int j = 0; j < 6; ++j) settle(box[o][j]);
         }
+      for (int tile0 = 0; tile0 < n_tiles; tile0 += grid, kk += K) {
+        const int n_here = min(grid, n_tiles - tile0);
+        if ((int)blockIdx.x >= n_here) break;
+        const int col0 = (tile0 + xcd_contiguous(blockIdx.x, n_here)) * NU;
+        const bool full = col0 + NU <= B;          // every column of this workgroup exists: no per-store mask
+        const bool mine = col0 + lane < B;
+        int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
+        if (AABB_HERE) settle(coll);               // landed before the tick loop (see above)
         for (int k = 0; k < K; ++k) {
             lds_barrier();                                             // slab k&1 is complete (stores of earlier ticks stay in flight)
-            const double *src = slab + (size_t)(k & 1) * NR * NU + lane;
+            const double *src = slab + (size_t)((kk + k) & 1) * NR * NU + lane;
             // one log (13 or 12 rows) at a time: every LDS read first, then every store, so that neither the
             // LDS latency nor the store path's acceptance time is paid per element
             if (LOG_STATE) {
-                double v[13][QPL];
+                double v[13];
 #pragma unroll
-                for (int r = 0; r < 13; ++r)
-#pragma unroll
-                    for (int q = 0; q < QPL; ++q) v[r][q] = src[r * NU + q * 64];
-                double *dst = state_log + (size_t)k * 13 * sB + col0;               // wave-uniform: lives in SGPRs
+                for (int r = 0; r < 13; ++r) v[r] = src[r * NU];
+                double *dst = state_log + (size_t)k * 13 * sP + col0;               // wave-uniform: lives in SGPRs
 #pragma unroll
                 for (int r = 0; r < 13; ++r) {
-#pragma unroll
-                    for (int q = 0; q < QPL; ++q)
-                        if (full || col0 + q * 64 + lane < B)                       // 512-B coalesced wave store
-                            store_uniform_base(dst + r * sB + q * 64, lane_bytes, v[r][q]);
+                    if (full || mine) store_uniform_base(dst + r * sP, lane_bytes, v[r]);      // 512-B coalesced wave store
                     // one obstacle between two stores: the comparisons issue while the store path takes the store
                     if (AABB_HERE && r < kBoxRegs && r < n_obs) {
-                        const double x = v[0][0], y = v[1][0], z = v[2][0];
+                        const double x = v[0], y = v[1], z = v[2];
                         const bool hit = (x >= box[r][0]) && (x <= box[r][1]) && (y >= box[r][2]) && (y <= box[r][3]) &&
                                          (z >= box[r][4]) && (z <= box[r][5]);      // inclusive, minimum_snap.py:352-357
                         coll |= hit ? 1 : 0;
                     }
                 }
                 if (AABB_HERE) {
-                    const double x = v[0][0], y = v[1][0], z = v[2][0];
+                    const double x = v[0], y = v[1], z = v[2];
                     for (int o = kBoxRegs; o < n_obs; ++o) {      // more obstacles than registers hold: the slow way
                         const double *c = aabbs + 6 * o;          // uniform address: scalar loads
                         const bool hit = (x >= c[0]) && (x <= c[1]) && (y >= c[2]) && (y <= c[3]) && (z >= c[4]) &&
@@ -221,25 +241,38 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 }
             }
             if (LOG_CMD) {
-                double v[UAVAC_CMD_COLS][QPL];
+                double v[UAVAC_CMD_COLS];
+#pragma unroll
+                for (int r = 0; r < UAVAC_CMD_COLS; ++r) v[r] = src[(CMD0 + r) * NU];
+                double *dst = cmd_log + (size_t)k * UAVAC_CMD_COLS * sP + col0;
 #pragma unroll
                 for (int r = 0; r < UAVAC_CMD_COLS; ++r)
-#pragma unroll
-                    for (int q = 0; q < QPL; ++q) v[r][q] = src[(CMD0 + r) * NU + q * 64];
-                double *dst = cmd_log + (size_t)k * UAVAC_CMD_COLS * sB + col0;
-#pragma unroll
-                for (int r = 0; r < UAVAC_CMD_COLS; ++r)
-#pragma unroll
-                    for (int q = 0; q < QPL; ++q)
-                        if (full || col0 + q * 64 + lane < B) store_uniform_base(dst + r * sB + q * 64, lane_bytes, v[r][q]);
+                    if (full || mine) store_uniform_base(dst + r * sP, lane_bytes, v[r]);
             }
         }
         if (AABB_HERE && mine) istate[2 * sB + col0 + lane] = coll;
+      }
         return;
     }
 
     // ---------------------------------------------------------------------------------- compute waves
     const int tid = threadIdx.x;
+    // The constants of the per-tick path, in vector registers (see vk() in control_law.h): with all of VehK in scalar
+    // registers the tick loop spilled SGPRs to VGPR lanes (v_readlane / v_writelane, 22 per tick) and rebuilt its fp64
+    // literals on every tick (60 s_mov_b32).  The outer block keeps reading its own constants from the kernel arguments.
+    VehK L = V;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { L.I[i] = vk(V.I[i]); L.inv_I[i] = vk(V.inv_I[i]); L.ikp[i] = vk(V.ikp[i]); }
+    L.arm = vk(V.arm); L.inv_arm = vk(V.inv_arm); L.kappa = vk(V.kappa); L.inv_kappa = vk(V.inv_kappa);
+    L.kf = vk(V.kf); L.inv_kf = vk(V.inv_kf);
+    L.lit_tiny = vk(V.lit_tiny); L.lit_h2_small = vk(V.lit_h2_small); L.lit_c8 = vk(V.lit_c8); L.lit_c6 = vk(V.lit_c6);
+    L.lit_c4 = vk(V.lit_c4); L.lit_s9 = vk(V.lit_s9); L.lit_s7 = vk(V.lit_s7); L.lit_s5 = vk(V.lit_s5); L.lit_s3 = vk(V.lit_s3);
+    L.lit_375 = vk(V.lit_375); L.lit_e_small = vk(V.lit_e_small);
+
+  for (int tile0 = 0; tile0 < n_tiles; tile0 += grid, kk += K) {
+    const int n_here = min(grid, n_tiles - tile0);
+    if ((int)blockIdx.x >= n_here) break;
+    const int col0 = (tile0 + xcd_contiguous(blockIdx.x, n_here)) * NU;
     const int b = col0 + tid;
     const bool live = b < B;
     const int bb = live ? b : B - 1;                                   // dead lanes shadow the last UAV, store nothing
@@ -351,18 +384,6 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     const double qn2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
     double inv_n2 = (fabs(qn2 - 1.0) < 1.0e-12) ? 1.0 : 1.0 / qn2;
 
-    // The constants of the per-tick path, in vector registers (see vk() in control_law.h): with all of VehK in scalar
-    // registers the tick loop spilled SGPRs to VGPR lanes (v_readlane / v_writelane, 22 per tick) and rebuilt its fp64
-    // literals on every tick (60 s_mov_b32).  The outer block keeps reading its own constants from the kernel arguments.
-    VehK L = V;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { L.I[i] = vk(V.I[i]); L.inv_I[i] = vk(V.inv_I[i]); L.ikp[i] = vk(V.ikp[i]); }
-    L.arm = vk(V.arm); L.inv_arm = vk(V.inv_arm); L.kappa = vk(V.kappa); L.inv_kappa = vk(V.inv_kappa);
-    L.kf = vk(V.kf); L.inv_kf = vk(V.inv_kf);
-    L.lit_tiny = vk(V.lit_tiny); L.lit_h2_small = vk(V.lit_h2_small); L.lit_c8 = vk(V.lit_c8); L.lit_c6 = vk(V.lit_c6);
-    L.lit_c4 = vk(V.lit_c4); L.lit_s9 = vk(V.lit_s9); L.lit_s7 = vk(V.lit_s7); L.lit_s5 = vk(V.lit_s5); L.lit_s3 = vk(V.lit_s3);
-    L.lit_375 = vk(V.lit_375); L.lit_e_small = vk(V.lit_e_small);
-
     for (int k = 0; k < K; ++k) {
         if (phase == 0 && nrows > 0) {
             // ------------------------------------------------------------- outer loop (main.py:47-61)
@@ -425,7 +446,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         // this wave's LDS writes then finds nothing outstanding (the launcher says when that pays)
         if (LOGGING && late_handover && k > 0) lds_barrier();
 
-        double *my = LOGGING ? slab + (size_t)(k & 1) * NR * NU + tid : nullptr;
+        double *my = LOGGING ? slab + (size_t)((kk + k) & 1) * NR * NU + tid : nullptr;
         if (LOG_CMD) {
             double *c = my + CMD0 * NU;
             c[0] = thrust_cmd; c[1 * NU] = pc; c[2 * NU] = qc; c[3 * NU] = rc;
@@ -456,15 +477,14 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             my[7 * NU] = vx; my[8 * NU] = vy; my[9 * NU] = vz;
             my[10 * NU] = wp; my[11 * NU] = wq; my[12 * NU] = wr;
         }
-        if (LOGGING && !late_handover) lds_barrier();        // hand slab k&1 to the store wave; it was drained two ticks ago
+        if (LOGGING && !late_handover) lds_barrier();        // hand slab (kk+k)&1 to the store wave; it was drained two ticks ago
         ++inner;
         phase = (phase + 1 == V.F) ? 0 : phase + 1;
     }
     if (LOGGING && late_handover && K > 0) lds_barrier();      // the last slab
 
     if (!POLY && nrows > 0) row_wait(nxt);          // nothing may stay in flight into these registers
-    if (!live) return;
-
+    if (live) {
     state[0 * sB + b] = px; state[1 * sB + b] = py; state[2 * sB + b] = pz;
     state[3 * sB + b] = q0; state[4 * sB + b] = q1; state[5 * sB + b] = q2; state[6 * sB + b] = q3;
     state[7 * sB + b] = vx; state[8 * sB + b] = vy; state[9 * sB + b] = vz;
@@ -484,6 +504,8 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         state[28 * sB + b] = yprev;
         state[29 * sB + b] = ysum;
     }
+    }
+  }
 }
 
 __global__ void state_init_kernel(const VehK V, const double *__restrict__ positions, int B, int hover,
@@ -504,14 +526,12 @@ __global__ void state_init_kernel(const VehK V, const double *__restrict__ posit
     for (int r = 0; r < UAVAC_ISTATE_ROWS; ++r) istate[r * sB + b] = 0;
 }
 
-constexpr int kColumnsPerLaunch = 256 * 4 * 64;          // one 64-UAV compute wave per SIMD of the chip
-
 // Empty kernel with the workgroup shape of the logged rollout (two waves).  Where the dispatcher puts the waves of a
 // 2-wave workgroup depends on the shape of the kernel that ran before: after the planning kernels (1-wave
 // workgroups) 5-15 % of the SIMDs receive two compute waves and others two store waves, and the launch runs 25 %
 // slower (tools/first_launch_bisect.py, tools/placement_after_sampler.py; it heals by itself over the next two
 // launches).  After ANY kernel of 2-wave workgroups the placement is one compute + one store wave on every SIMD.
-__global__ void __launch_bounds__(128) rollout_align_kernel() {}
+__global__ void __launch_bounds__(256) rollout_align_kernel() {}
 
 // One compute + one store wave per 64 UAVs, one hand-over per tick.  (Two ticks per hand-over -- the compute wave fills two
 // slabs before the barrier, the store wave drains two after it; 2 x 2 slabs + the coefficient tile still fit four workgroups
@@ -529,26 +549,38 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     constexpr bool LOGGING = LS || LC || WATCH;
     constexpr int NU = 64 * CW;
     constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0) + (WATCH ? 3 : 0);
-    constexpr int threads = NU + (LOGGING ? 64 * SW : 0);
+    const int n_tiles_ = (B + NU - 1) / NU;
+    constexpr int nsw = 1;
+    // a placeholder wave between compute and store wave where two workgroups share a CU (257 .. 512 tiles on 1 024 SIMDs)
+    int n_idle = 0;
+    if (LOGGING) {
+        if (ctx->idle_waves >= 0) n_idle = ctx->idle_waves > 1 ? 1 : ctx->idle_waves;
+        else n_idle = (4 * n_tiles_ > ctx->n_simds && 2 * n_tiles_ <= ctx->n_simds) ? 1 : 0;
+    }
+    const int threads = NU + (LOGGING ? 64 * (nsw + n_idle) : 0);
     const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0));
     auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    // With logs, batches beyond one compute wave per SIMD go out as consecutive launches of kColumnsPerLaunch UAVs:
-    // measured per 1 000 ticks, B = 131 072 in one launch 4.04 ms, as 2 x 65 536 3.3 ms (two workgroups per SIMD
-    // make the compute and store waves of a CU queue on each other).  Results do not depend on the split.
-    const int per_launch = LOGGING ? kColumnsPerLaunch : B;
-    for (int base = 0; base < B; base += per_launch) {
-        const int cols = (B - base < per_launch) ? B - base : per_launch;
-        const int grid = (cols + NU - 1) / NU;
-        // Hand the slab over at the end of the tick, or a third of a tick later (after the next tick's motor model)?  Results
-        // are the same bit for bit; per 1 000 logged ticks, end-of-tick / late: 0.905 / 0.880 ms at 8 192 and 16 384 columns,
-        // 0.979 / 0.985 at 24 576, 0.996 / 1.044 at 32 768, 1.16 / 1.11-1.14 at 49 152, 1.33 / 1.30 at 65 536.
-        const int late = (cols > 20480 && cols < 40960) ? 0 : 1;
-        if (LOGGING && ctx->rollout_align)
-            hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(128), 0, ctx->stream);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, V, traj, row_offsets, state, istate, B, K,
-                           state_log, cmd_log, aabbs, n_obs, base, P, late);
-    }
+    if (lds + (size_t)ctx->lds_pad > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)ctx->lds_pad));
+    // With a second wave per workgroup the launch holds at most one workgroup per SIMD; a batch with more 64-UAV tiles than
+    // the chip has SIMDs is walked by those workgroups pass after pass inside ONE launch (persistent tiles, see the kernel).
+    // Round 2 issued one launch per 65 536 columns instead (a single launch with two workgroups per SIMD had been measured
+    // at 4.04 ms per 1 000 ticks for B = 131 072 against 3.15 ms for two launches): every launch boundary made all SIMDs
+    // wait for the slowest one.  Without a second wave one launch of all tiles is kept (two compute waves per SIMD hide
+    // each other's latency).  Results do not depend on the split.
+    const int n_tiles = (B + NU - 1) / NU;
+    const int max_wgs = ctx->n_simds / CW;                     // one compute wave per SIMD at most
+    const int grid = (LOGGING && n_tiles > max_wgs) ? max_wgs : n_tiles;
+    const int cols = grid * NU < B ? grid * NU : B;            // columns in flight at a time
+    // Hand the slab over at the end of the tick, or a third of a tick later (after the next tick's motor model)?  Results
+    // are the same bit for bit; per 1 000 logged ticks, end-of-tick / late: 0.905 / 0.880 ms at 8 192 and 16 384 columns,
+    // 0.979 / 0.985 at 24 576, 0.996 / 1.044 at 32 768, 1.16 / 1.11-1.14 at 49 152, 1.33 / 1.30 at 65 536.
+    const int late = ctx->late_handover >= 0 ? ctx->late_handover : ((cols > 20480 && cols < 40960) ? 0 : 1);
+    const size_t pitch = (LS || LC) ? (ctx->log_pitch > 0 ? (size_t)ctx->log_pitch : (size_t)B) : (size_t)B;
+    if (LOGGING && ctx->rollout_align)
+        hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(threads), 0, ctx->stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds + (size_t)ctx->lds_pad, ctx->stream, V, traj, row_offsets, state, istate,
+                       B, K, state_log, cmd_log, aabbs, n_obs, n_tiles, pitch, P, late, n_idle);
     auto tf = [](bool v) { return v ? "true" : "false"; };
     char name[176];
     snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),

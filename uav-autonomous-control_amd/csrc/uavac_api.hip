@@ -239,6 +239,11 @@ int uavac_create(uavac_ctx **out, int device_id) {
     }
     if (const char *e = getenv("UAVAC_YAW_GROUP")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 16) ctx->yaw_group = v; }
     if (const char *e = getenv("UAVAC_ROLLOUT_ALIGN")) ctx->rollout_align = (e[0] == '0') ? 0 : 1;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0)
+            ctx->n_simds = 4 * cus;
+    }
     *out = ctx;
     return UAVAC_OK;
 }
@@ -289,6 +294,16 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
         ctx->yaw_group = value;
     } else if (n == "rollout_align") {
         ctx->rollout_align = value ? 1 : 0;
+    } else if (n == "log_pitch") {
+        if (value < 0) return uavac_fail(ctx, UAVAC_EINVAL, "log_pitch is 0 (= B) or a number of doubles >= B");
+        ctx->log_pitch = value;
+    } else if (n == "late_handover") {
+        ctx->late_handover = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "idle_waves") {
+        ctx->idle_waves = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "lds_pad") {
+        if (value < 0 || value > 120 * 1024) return uavac_fail(ctx, UAVAC_EINVAL, "lds_pad is 0 .. 122880 bytes");
+        ctx->lds_pad = value & ~7;
     } else {
         return uavac_fail(ctx, UAVAC_EINVAL, "unknown option");
     }
@@ -689,6 +704,8 @@ int uavac_control_rollout_dev(uavac_ctx *ctx, const uavac_vehicle *V, const doub
     if (B < 1 || K < 0 || !traj || !row_offsets || !state || !istate || n_obs < 0)
         return uavac_fail(ctx, UAVAC_EINVAL, "bad size or null pointer");
     if (K == 0) return UAVAC_OK;
+    if ((state_log || cmd_log) && ctx->log_pitch > 0 && ctx->log_pitch < B)
+        return uavac_fail(ctx, UAVAC_EINVAL, "option log_pitch is smaller than B");
     return uavac_launch_rollout(ctx, uavac_make_vehk(*V), traj, row_offsets, state, istate, B, K, state_log, cmd_log,
                                 aabbs, n_obs);
 }
@@ -705,6 +722,8 @@ int uavac_control_rollout_plan_dev(uavac_ctx *ctx, const uavac_vehicle *V, const
     if (!yaw && !first_yaw) return uavac_fail(ctx, UAVAC_EINVAL, "need the dense yaw column or the missions' first headings");
     if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
     if (K == 0) return UAVAC_OK;
+    if ((state_log || cmd_log) && ctx->log_pitch > 0 && ctx->log_pitch < B)
+        return uavac_fail(ctx, UAVAC_EINVAL, "option log_pitch is smaller than B");
     PlanRef plan;
     plan.coeffs = coeffs; plan.seg_rows = seg_rows; plan.yaw = yaw; plan.first_yaw = first_yaw; plan.dt = dt; plan.m = m;
     return uavac_launch_rollout(ctx, uavac_make_vehk(*V), nullptr, row_offsets, state, istate, B, K, state_log, cmd_log,
@@ -722,6 +741,8 @@ int uavac_control_rollout_plan_ragged_dev(uavac_ctx *ctx, const uavac_vehicle *V
         return uavac_fail(ctx, UAVAC_EINVAL, "bad size or null pointer");
     if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
     if (K == 0) return UAVAC_OK;
+    if ((state_log || cmd_log) && ctx->log_pitch > 0 && ctx->log_pitch < B)
+        return uavac_fail(ctx, UAVAC_EINVAL, "option log_pitch is smaller than B");
     PlanRef plan;
     plan.coeffs = coeffs; plan.seg_rows = seg_rows; plan.first_yaw = first_yaw; plan.dt = dt; plan.m = max_m;
     plan.seg_offsets = seg_offsets;
@@ -784,7 +805,13 @@ int uavac_control_rollout(uavac_ctx *ctx, const uavac_vehicle *V, const double *
     if (int rc = h2d_staged(ctx, ds, state, ns * 8)) return rc;
     if (int rc = h2d_staged(ctx, di, istate, ni * 4)) return rc;
     if (obs) if (int rc = h2d_staged(ctx, dab, aabbs, (size_t)n_obs * 48)) return rc;
-    if (int rc = uavac_control_rollout_dev(ctx, V, dtr, dro, ds, di, B, K, dsl, dcl, dab, obs ? n_obs : 0)) return rc;
+    {
+        const int64_t pitch = ctx->log_pitch;          // the host logs are dense [K][13 | 12][B]
+        ctx->log_pitch = 0;
+        const int rc = uavac_control_rollout_dev(ctx, V, dtr, dro, ds, di, B, K, dsl, dcl, dab, obs ? n_obs : 0);
+        ctx->log_pitch = pitch;
+        if (rc) return rc;
+    }
     if (int rc = d2h_staged(ctx, state, ds, ns * 8)) return rc;
     if (int rc = d2h_staged(ctx, istate, di, ni * 4)) return rc;
     if (state_log) if (int rc = d2h_staged(ctx, state_log, dsl, nsl * 8)) return rc;

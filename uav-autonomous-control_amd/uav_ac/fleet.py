@@ -630,13 +630,42 @@ class Fleet:
         Returns (state_log (K,13,B) | None, cmd_log (K,12,B) | None).
         """
         e, torch = self.engine, self.engine._torch
-        if state_log is True:
-            state_log = torch.empty((K, 13, self.B), dtype=torch.float64, device=e.device)
-        if cmd_log is True:
-            cmd_log = torch.empty((K, nat.CMD_COLS, self.B), dtype=torch.float64, device=e.device)
+        # Log rows are `pitch` doubles apart.  A log allocated here gets a pitch that is a multiple of 16 (rows on 128-byte
+        # lines: B = 65 534 at pitch B streams at half the rate of 65 536) and is returned as the (K, rows, B) view of it; a
+        # caller's 3-D tensor (K, rows, P >= B) is written with pitch P; anything else contiguous with pitch B.
+        views, pitch = {}, None
         for name, t, rows in (("state_log", state_log, 13), ("cmd_log", cmd_log, nat.CMD_COLS)):
-            if t is not None and (t.dtype != torch.float64 or not t.is_contiguous() or t.numel() < K * rows * self.B):
+            if t is None:
+                continue
+            if t is True:
+                want = -(-self.B // 16) * 16
+                if pitch not in (None, want):
+                    raise ValueError("state_log and cmd_log must have the same row pitch")
+                pitch = want
+                t = torch.empty((K, rows, pitch), dtype=torch.float64, device=e.device)
+                views[name] = (t, t[:, :, :self.B])
+                continue
+            if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() < K * rows * self.B:
                 raise ValueError(f"{name} must be a contiguous float64 tensor with >= K*{rows}*B elements")
+            p_ = int(t.shape[2]) if (t.dim() == 3 and t.shape[1] == rows and t.shape[2] >= self.B and t.shape[0] >= K) else self.B
+            if pitch not in (None, p_):
+                raise ValueError("state_log and cmd_log must have the same row pitch")
+            pitch = p_
+            views[name] = (t, t)
+        state_log, state_view = views.get("state_log", (None, None))
+        cmd_log, cmd_view = views.get("cmd_log", (None, None))
+        pitched = pitch is not None and pitch != self.B
+        if pitched:
+            e.ctx.set_option("log_pitch", pitch)
+        try:
+            self._launch_rollout(K, state_log, cmd_log, aabbs)
+        finally:
+            if pitched:                       # the option belongs to this call: other users of the ctx get pitch = B
+                e.ctx.set_option("log_pitch", 0)
+        return state_view, cmd_view
+
+    def _launch_rollout(self, K, state_log, cmd_log, aabbs):
+        e, torch = self.engine, self.engine._torch
         ab, n_obs = None, 0
         if aabbs is not None:
             ab = e._dev(aabbs, torch.float64).reshape(-1, 6)
@@ -670,7 +699,6 @@ class Fleet:
         else:
             e.ctx.call("uavac_control_rollout_dev", C.byref(self.vehicle), _ptr(p.traj), _ptr(p.row_offsets),
                        _ptr(self.state), _ptr(self.istate), self.B, int(K), _ptr(state_log), _ptr(cmd_log), _ptr(ab), n_obs)
-        return state_log, cmd_log
 
     def step(self):
         """One tick: `tc.step()` + `simulation.step()` for every UAV (main.py:37-45, mujoco_sim.py:144-151)."""
