@@ -232,3 +232,48 @@ def test_placeholder_wave_between_compute_and_store_wave_changes_no_bit(eng):
         logs.append(f.rollout(60, state_log=True)[0])
     eng.ctx.set_option("idle_waves", -1)
     assert torch.equal(logs[0], logs[1])
+
+
+@pytest.mark.parametrize("waves", [4, 8, 16])
+def test_wide_sampler_equals_the_one_wave_sampler_bit_for_bit(eng, waves):
+    """minsnap_sample_wide.hip (W wavefronts per mission, the yaw scan combined across waves through LDS) against
+    minsnap_sample.hip (one wavefront walks the mission): rows and first headings, bit for bit -- on the 8(d) missions, on
+    missions that climb vertically for more than a round of 1 024 rows before their first heading (placeholders patched
+    across waves), on missions that circle (headings wrap: the slow, ordered path of the scan) and on one-row legs."""
+    import torch
+    rng = np.random.default_rng(77 + waves)
+    cases = [(_missions(300, 12), 3.0, 0.01), (_missions(64, 1), 3.0, 0.01), (_missions(50, 20), 0.9, 0.004)]
+    # long vertical climb (no heading for 1 800-2 700 rows), then a horizontal course
+    climb = []
+    for i in range(40):
+        h = rng.uniform(8.0, 12.0)
+        p0 = np.array([rng.uniform(0, 5), rng.uniform(0, 5), -1.0])
+        legs = np.cumsum(rng.uniform(-3, 3, (5, 3)) * np.array([1, 1, 0.1]), axis=0)
+        climb.append(np.vstack([p0, p0 + [0, 0, -h], p0 + [0, 0, -h] + legs]))
+    cases.append((np.stack(climb), 1.0, 0.01))
+    # circles: three and a half turns, both senses -> np.unwrap corrections in many 64-row chunks
+    circ = []
+    for i in range(40):
+        n, sense = 29, (1 if i % 2 else -1)
+        th = sense * np.linspace(0, 7 * np.pi, n) + rng.uniform(0, 2 * np.pi)
+        rad = rng.uniform(1.5, 4.0)
+        circ.append(np.stack([10 + rad * np.cos(th), 10 + rad * np.sin(th), -3 + 0.1 * np.sin(3 * th)], axis=1))
+    cases.append((np.stack(circ), 2.0, 0.01))
+    # very short legs (1-3 rows per spline) and a coarse step
+    cases.append((_missions(100, 6) * 0.02, 3.0, 0.01))
+    for wps, v, dt in cases:
+        got = {}
+        for sw in (1, waves):
+            eng.ctx.set_option("sampler_waves", sw)
+            try:
+                plan = eng.plan(wps, v, dt)
+                plan.traj.fill_(float("nan"))
+                plan.first_yaw.fill_(float("nan"))
+                eng.replan(plan)                               # the one-call chain takes the same sampler
+                assert eng.take_flags() == [0, 0, 0, 0]
+                got[sw] = (plan.traj.clone(), plan.first_yaw.clone(), plan.row_offsets.clone())
+            finally:
+                eng.ctx.set_option("sampler_waves", 1)
+        assert torch.equal(got[1][2], got[waves][2])
+        assert not bool(torch.isnan(got[waves][0]).any())
+        assert torch.equal(got[1][0], got[waves][0]) and torch.equal(got[1][1], got[waves][1])

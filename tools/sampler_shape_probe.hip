@@ -4,6 +4,8 @@
 //   A  one wave per mission, 64-row chunks one after the other           (the shipped shape)
 //   B  four waves per mission, chunk c by wave c % 4, a barrier per round (22.5 KB per round and mission)
 //   C  one wave per chunk, chunks in memory order                         (a compact front, like a fill)
+//   D  eight waves per mission (45 KB per round), E  sixteen (90 KB per round: a mission in two rounds)   (round 3)
+//   F  like A, but the missions of an XCD are visited with a stride of 37 (neighbouring waves far apart)     (round 3)
 // Build: hipcc --offload-arch=gfx950 -O3 tools/sampler_shape_probe.hip -o tools/sampler_shape_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -31,6 +33,20 @@ __global__ void __launch_bounds__(256) shapeB(double *traj) {
         __builtin_amdgcn_s_barrier();
     }
 }
+template <int W>
+__global__ void __launch_bounds__(64 * W) shapeW(double *traj) {
+    double *base = traj + xcd_mission(blockIdx.x, gridDim.x) * R * 11;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c0 = 0; c0 * 64 < R; c0 += W) {
+        if ((c0 + w) * 64 < R) chunk(base, c0 + w, lane);
+        __builtin_amdgcn_s_barrier();
+    }
+}
+__global__ void __launch_bounds__(64) shapeF(double *traj) {
+    const size_t n = gridDim.x, per = n / 8, x = blockIdx.x % 8, i = blockIdx.x / 8;
+    double *base = traj + (x * per + (i * 37) % per) * R * 11;          // 37 and 8192 are coprime: a permutation
+    for (int c = 0; c * 64 < R; ++c) chunk(base, c, threadIdx.x);
+}
 __global__ void __launch_bounds__(64) shapeC(double *traj, int chunks_per_mission) {
     const size_t g = xcd_mission(blockIdx.x, gridDim.x);
     const size_t mission = g / chunks_per_mission;
@@ -46,7 +62,10 @@ int main() {
         auto go = [&] {
             if (shape == 0) shapeA<<<B, 64>>>(t);
             else if (shape == 1) shapeB<<<B, 256>>>(t);
-            else shapeC<<<B * cpm, 64>>>(t, cpm);
+            else if (shape == 2) shapeC<<<B * cpm, 64>>>(t, cpm);
+            else if (shape == 3) shapeW<8><<<B, 512>>>(t);
+            else if (shape == 4) shapeW<16><<<B, 1024>>>(t);
+            else shapeF<<<B, 64>>>(t);
         };
         go(); go();
         (void)hipEventRecord(e0);
@@ -56,7 +75,7 @@ int main() {
         return ms / 5;
     };
     for (int rep = 0; rep < 2; ++rep)
-        for (int shape = 0; shape < 3; ++shape) {
+        for (int shape = 0; shape < 6; ++shape) {
             printf("shape %c:", 'A' + shape);
             for (auto p : bufs) printf(" %.3f", timed(shape, p));
             printf("  ms per buffer\n");

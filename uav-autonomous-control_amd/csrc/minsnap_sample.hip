@@ -296,6 +296,10 @@ int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg
                  (x.yaw_dense ? sizeof(double) * yg * SB : 0);
     const bool hits = x.aabb && x.hit, derivs = x.jerk || x.snap;
     const bool ragged = x.seg_offsets != nullptr;
+    // rows (+ first headings) only, one segment count for the batch: the W-waves-per-mission kernel (minsnap_sample_wide.hip)
+    if (plain && !ragged && !x.yaw_dense && ctx->sampler_waves > 1)
+        return uavac_launch_sample_wide(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x.capacity_rows, x.first_yaw,
+                                        ctx->sampler_waves);
     if (ragged && (derivs || x.yaw_dense || x.total_segments < 0))
         return uavac_fail(ctx, UAVAC_EINVAL, "ragged sampling: rows (+ hit flags, first yaws) only, and the segment total");
     if (hits)
