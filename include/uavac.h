@@ -222,6 +222,26 @@ int uavac_minsnap_sample_ragged_dev(uavac_ctx *ctx, const double *coeffs, const 
                                     int64_t total_segments, double dt, double *traj,
                                     int64_t traj_capacity_rows, const double *aabb, int32_t *hit,
                                     double *first_yaw);
+/* ONE ROUND of the obstacle loop of MinimumSnap._generate_collision_free_trajectory (minimum_snap.py:81-93) for B ragged
+ * missions against one cuboid aabb[6], entirely on the device (no rows are stored: inside the loop only the hit flags
+ * matter; sample the final waypoints once with uavac_minsnap_*_ragged_dev afterwards):
+ *   - the missions with active[b] != 0 are planned (durations, row counts, coefficient solve) -- the others are left alone;
+ *   - every spline of an active mission with a sample inside the cuboid (inclusive test, is_collision_cuboid :327-357,
+ *     on the very positions the sampler would store) gets the midpoint of its two waypoints inserted before its end
+ *     waypoint (insert_midpoints_at_indexes :359-391): wp_out / seg_offsets_out are the waypoint arrays of the next round
+ *     (all B missions; untouched ones are copied), laid out like wp / seg_offsets;
+ *   - an active mission without a hit is clean for this cuboid: active[b] = 0; one that would outgrow UAVAC_MAX_SEGMENTS is
+ *     left as it is: active[b] = 0, overflow[b] = 1; a mission that received midpoints: touched[b] = 1, stays active;
+ *   - counters [4] i32 (device): missions still active, missions that outgrew UAVAC_MAX_SEGMENTS in this round, the largest segment
+ *     count after the round (a valid max_m for the next one), the segment total of the batch after the round.
+ * max_m >= every mission's segment count, <= UAVAC_MAX_SEGMENTS.  Scratch (device, caller-owned, S_cap >= the segment
+ * total before the round): times [S_cap], seg_rows [S_cap] i32, row_offsets [B+1], coeffs [S_cap][8][3], hit [S_cap] i32;
+ * wp_out holds S_cap_next + B waypoints with S_cap_next >= the segment total after the round (at most twice the one before). */
+int uavac_minsnap_obstacle_round_dev(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, int max_m,
+                                     double velocity, double dt, const double *aabb, int32_t *active, int32_t *overflow,
+                                     int32_t *touched, double *wp_out, int64_t *seg_offsets_out, int32_t *counters,
+                                     double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs, int32_t *hit);
+
 /* MinimumSnap._calculate_yaws (minimum_snap.py:126-136) on its own, for B independent velocity
  * sequences of any length: sequence b = rows [offsets[b], offsets[b+1]) of velocities[.][3] (only
  * vx, vy are read); yaws[offsets[B]].  Headings of rows with |v_xy| >= 1e-3, np.unwrap over those,

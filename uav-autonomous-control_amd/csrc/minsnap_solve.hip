@@ -394,6 +394,21 @@ static int ensure_totals(uavac_ctx *ctx, int B, int64_t **tiles) {
     return UAVAC_OK;
 }
 
+int uavac_ensure_totals(uavac_ctx *ctx, int B, int32_t **totals, int64_t **tile_sums) {
+    if (int rc = ensure_totals(ctx, B, tile_sums)) return rc;
+    *totals = ctx->d_totals;
+    return UAVAC_OK;
+}
+
+int uavac_launch_totals_scan(uavac_ctx *ctx, int B, int64_t *out) {
+    const int n_tiles = (B + 255) / 256;
+    int64_t *tiles = nullptr;
+    if (int rc = ensure_totals(ctx, B, &tiles)) return rc;
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, ctx->d_totals, B, tiles, out);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
+
 int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                             double *times, int32_t *seg_rows, int64_t *row_offsets, const int64_t *seg_offsets) {
     const int n_tiles = (B + 255) / 256;

@@ -184,10 +184,17 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
                                                              int32_t *__restrict__ status,
                                                              int32_t *__restrict__ flags,
                                                              const int64_t *__restrict__ seg_offsets,
-                                                             const int64_t *__restrict__ guard_rows, int64_t guard_capacity) {
+                                                             const int64_t *__restrict__ guard_rows, int64_t guard_capacity,
+                                                             const int32_t *__restrict__ active) {
     // part of a planning chain whose rows would not fit the caller's buffer (uavac_minsnap_plan_dev): the plan is refused as
     // a whole and the coefficients stay what they were (uniform over the launch; one scalar load)
     if (guard_rows && *guard_rows > guard_capacity) return;
+    // obstacle loop (uavac_minsnap_obstacle_round_dev): only the missions still being corrected are re-solved -- a wave none
+    // of whose missions is active leaves at once (the others solve all 64: their coefficients are simply the same as before)
+    if (active) {
+        const int b_ = blockIdx.x * TB + threadIdx.x;
+        if (!__any(b_ < B && active[b_] != 0)) return;
+    }
     __shared__ double stage[TB * 25];                 // one segment's 24 coefficients per mission (+1 pad)
     __shared__ int64_t seg0_of[RAGGED ? TB : 1];      // ragged: first segment and segment count of every mission of the wave
     __shared__ int m_of[RAGGED ? TB : 1];
@@ -380,7 +387,8 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
 }  // namespace
 
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
-                          int32_t *status, const int64_t *seg_offsets, const int64_t *guard_rows, int64_t guard_capacity) {
+                          int32_t *status, const int64_t *seg_offsets, const int64_t *guard_rows, int64_t guard_capacity,
+                          const int32_t *active) {
     const size_t need = (size_t)(m > 1 ? m - 1 : 1) * 28 * (size_t)B;
     if (need > ctx->ws_cap) {
         if (ctx->d_ws) UAVAC_HIP(ctx, hipFree(ctx->d_ws));
@@ -391,10 +399,10 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
     }
     if (seg_offsets)
         hipLaunchKernelGGL(minsnap_solve_bt_kernel<true>, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
-                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets, guard_rows, guard_capacity);
+                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets, guard_rows, guard_capacity, active);
     else
         hipLaunchKernelGGL(minsnap_solve_bt_kernel<false>, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
-                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets, guard_rows, guard_capacity);
+                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets, guard_rows, guard_capacity, active);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

@@ -508,6 +508,24 @@ int uavac_minsnap_row_offsets_dev(uavac_ctx *ctx, const int32_t *seg_rows, int B
     return uavac_launch_row_offsets(ctx, seg_rows, B, m, row_offsets);
 }
 
+int uavac_minsnap_obstacle_round_dev(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, int max_m,
+                                     double velocity, double dt, const double *aabb, int32_t *active, int32_t *overflow,
+                                     int32_t *touched, double *wp_out, int64_t *seg_offsets_out, int32_t *counters,
+                                     double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs, int32_t *hit) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_plan_args(ctx, wp, B, max_m)) return rc;
+    if (!seg_offsets || !aabb || !active || !overflow || !touched || !wp_out || !seg_offsets_out || !counters || !times ||
+        !seg_rows || !row_offsets || !coeffs || !hit)
+        return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (!std::isfinite(velocity) || !std::isfinite(dt)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite velocity or dt");
+    if (!(velocity > 0.0) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity and dt must be > 0");
+    UAVAC_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), ctx->stream));
+    if (int rc = uavac_launch_row_counts(ctx, wp, B, max_m, velocity, dt, times, seg_rows, row_offsets, seg_offsets)) return rc;
+    if (int rc = uavac_launch_solve_bt(ctx, wp, times, B, max_m, coeffs, nullptr, seg_offsets, nullptr, 0, active)) return rc;
+    return uavac_launch_obstacle_scan_and_insert(ctx, wp, seg_offsets, coeffs, seg_rows, B, max_m, dt, aabb, active, overflow,
+                                                 touched, hit, wp_out, seg_offsets_out, counters);
+}
+
 int uavac_yaw_scan_dev(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B, double *yaws) {
     UAVAC_ENTER(ctx);
     if (!velocities || !offsets || !yaws || B < 1) return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");

@@ -144,10 +144,19 @@ int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, doub
 // guard_rows (device, may be NULL): the launch does nothing when *guard_rows > guard_capacity (a refused planning chain)
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                           int32_t *status, const int64_t *seg_offsets = nullptr, const int64_t *guard_rows = nullptr,
-                          int64_t guard_capacity = 0);
+                          int64_t guard_capacity = 0, const int32_t *active = nullptr);
+// One round of the obstacle loop on the device (minsnap_obstacles.hip): collision scan of the active missions' splines
+// (no rows stored) + midpoint insertion into the next waypoint arrays
+int uavac_launch_obstacle_scan_and_insert(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, const double *coeffs,
+                                          const int32_t *seg_rows, int B, int max_m, double dt, const double *aabb,
+                                          int32_t *active, int32_t *overflow, int32_t *touched, int32_t *hit, double *wp_out,
+                                          int64_t *seg_offsets_out, int32_t *counters);
 // row_offsets [B+1] from per-segment row counts that exist already (minsnap_solve.hip)
 int uavac_launch_row_offsets(uavac_ctx *ctx, const int32_t *seg_rows, int B, int m, int64_t *row_offsets,
                              const int64_t *seg_offsets = nullptr);
+// exclusive prefix sum of ctx->d_totals [B] (filled by the caller's kernel together with the tile sums) -> out [B+1] i64
+int uavac_launch_totals_scan(uavac_ctx *ctx, int B, int64_t *out);
+int uavac_ensure_totals(uavac_ctx *ctx, int B, int32_t **totals, int64_t **tile_sums);
 // times / seg_rows / row_offsets from scratch into the caller's arrays unless row_offsets_s[B] > capacity_rows
 int uavac_launch_plan_commit(uavac_ctx *ctx, const double *times_s, const int32_t *seg_rows_s, const int64_t *row_offsets_s,
                              int B, int m, int64_t capacity_rows, double *times, int32_t *seg_rows, int64_t *row_offsets);

@@ -317,16 +317,20 @@ class Engine:
         return yaws
 
     def plan_collision_free(self, waypoints, obstacles, velocity: float = 1.0, dt: float = 0.01,
-                            max_iterations: int = 64, strict: bool = True, recheck_passes: int = 0) -> RaggedPlan:
+                            max_iterations: int = 64, strict: bool = True, recheck_passes: int = 0,
+                            device_loop: bool = True) -> RaggedPlan:
         """Batched `MinimumSnap(path, obstacles, velocity, dt).get_trajectory()` with obstacles
         (minimum_snap.py:63-95) for B missions at once.
 
         Per mission the reference's semantics are kept: obstacles are visited in order; for each one the mission is
         planned, every spline with a sample inside the cuboid gets a midpoint inserted before its end waypoint,
         and it is re-planned until clean; earlier obstacles are not re-checked.  Here all missions advance
-        together: each round plans every still-active mission in ONE ragged batch (`plan_ragged`: their segment counts
-        differ as soon as one has received a midpoint) and the sampler itself reports the hit splines; only the midpoint
-        insertion is host work.
+        together, and a round is ONE call into the C ABI (`uavac_minsnap_obstacle_round_dev`): the still-active missions
+        are planned as a ragged batch, their splines scanned for samples inside the cuboid (no rows are stored inside the
+        loop), and the midpoints inserted into the next round's waypoint arrays by a kernel; the host reads back four
+        counters per round.  The trajectories are sampled once, from the final waypoints.  `device_loop=False` runs round
+        2's loop instead (rows sampled in every round, hit flags to the host, midpoints inserted with NumPy): same
+        waypoints, kept for comparison.
         `waypoints`: (B, m+1, 3) array or a list of (m_b+1, 3) arrays.  The loop is bounded (the reference's is
         not: it cannot end when a waypoint lies inside a cuboid, or when a leg crosses one squarely).  A mission
         that exhausts `max_iterations` or UAVAC_MAX_SEGMENTS raises RuntimeError when `strict`; otherwise it is
@@ -335,6 +339,87 @@ class Engine:
         obstacle list again (up to that many extra passes, until a pass inserts nothing), which removes the
         conflicts a late midpoint can create with an earlier obstacle.
         """
+        if device_loop:
+            return self._plan_collision_free_device(waypoints, obstacles, velocity, dt, max_iterations, strict, recheck_passes)
+        return self._plan_collision_free_host(waypoints, obstacles, velocity, dt, max_iterations, strict, recheck_passes)
+
+    def _plan_collision_free_device(self, waypoints, obstacles, velocity, dt, max_iterations, strict, recheck_passes) -> RaggedPlan:
+        torch = self._torch
+        wps = [np.ascontiguousarray(w, dtype=np.float64) for w in waypoints]
+        B = len(wps)
+        if B == 0 or any(w.ndim != 2 or w.shape[1] != 3 or w.shape[0] < 2 for w in wps):
+            raise ValueError("waypoints must be B arrays of shape (m+1, 3)")
+        M = nat.MAX_SEGMENTS
+        counts = np.array([w.shape[0] - 1 for w in wps], dtype=np.int64)
+        if counts.max() > M:
+            raise ValueError(f"a mission has {int(counts.max())} segments; at most {M}")
+        cuboids = np.zeros((0, 6)) if obstacles is None else np.asarray(obstacles, dtype=np.float64).reshape(-1, 6)
+        so_host = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(counts, out=so_host[1:])
+        kw = dict(device=self.device)
+        S_cap = B * M                                           # no mission ever has more than M segments
+        wp_a = torch.empty((S_cap + B, 3), dtype=torch.float64, **kw)
+        wp_b = torch.empty_like(wp_a)
+        wp_a[:int(so_host[-1]) + B] = self._dev(np.concatenate(wps, axis=0), torch.float64)
+        so_a, so_b = self._dev(so_host, torch.int64), torch.empty((B + 1,), dtype=torch.int64, **kw)
+        failed = torch.zeros((B,), dtype=torch.int32, **kw)
+        max_m = int(counts.max())
+        if len(cuboids):
+            times = torch.empty((S_cap,), dtype=torch.float64, **kw)
+            seg_rows = torch.empty((S_cap,), dtype=torch.int32, **kw)
+            row_offsets = torch.empty((B + 1,), dtype=torch.int64, **kw)
+            coeffs = torch.empty((S_cap, 8, 3), dtype=torch.float64, **kw)
+            hit = torch.empty((S_cap,), dtype=torch.int32, **kw)
+            active = torch.empty((B,), dtype=torch.int32, **kw)
+            overflow = torch.zeros((B,), dtype=torch.int32, **kw)
+            touched = torch.zeros((B,), dtype=torch.int32, **kw)
+            counters = torch.zeros((4,), dtype=torch.int32, **kw)
+            cub_dev = self._dev(cuboids, torch.float64)
+            todo = torch.ones((B,), dtype=torch.int32, **kw)
+            self._bind_stream()
+            for sweep in range(1 + max(0, int(recheck_passes))):
+                touched.zero_()
+                for ci in range(len(cuboids)):
+                    torch.mul(todo, 1 - failed, out=active)
+                    n_active = int(active.sum().item())
+                    for it in range(max_iterations + 1):
+                        if n_active == 0:
+                            break
+                        self.ctx.call("uavac_minsnap_obstacle_round_dev", _ptr(wp_a), _ptr(so_a), B, max_m, float(velocity), float(dt),
+                                      _ptr(cub_dev[ci]), _ptr(active), _ptr(overflow), _ptr(touched), _ptr(wp_b), _ptr(so_b),
+                                      _ptr(counters), _ptr(times), _ptr(seg_rows), _ptr(row_offsets), _ptr(coeffs), _ptr(hit))
+                        wp_a, wp_b, so_a, so_b = wp_b, wp_a, so_b, so_a
+                        n_active, n_over, max_m, _total = (int(v) for v in counters.tolist())      # the round's one read-back
+                        if n_over:
+                            if strict:
+                                raise RuntimeError(f"obstacle correction needs more than {M} splines")
+                            failed.logical_or_(overflow)                 # stays as it is, reported in `converged`
+                    else:
+                        if n_active:
+                            if strict:
+                                raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
+                            failed.logical_or_(active)
+                todo = touched * (1 - failed)                          # only missions that changed can have new conflicts
+                if int(todo.sum().item()) == 0:
+                    break
+            flags = self.take_flags()
+            if flags[0]:
+                raise ValueError("non-finite waypoint or segment duration")
+        # the trajectories, once, from the final waypoints
+        so_final = so_a.cpu().numpy()
+        S = int(so_final[-1])
+        wp_final = wp_a[:S + B]
+        batch = self._plan_ragged_tensors(wp_final, so_a, so_final, int((so_final[1:] - so_final[:-1]).max()), velocity, dt, None)
+        if strict:
+            self.check(batch)
+        wp_host = wp_final.cpu().numpy()
+        final_wps = [wp_host[so_final[b] + b:so_final[b + 1] + b + 1].copy() for b in range(B)]
+        converged = ~failed.cpu().numpy().astype(bool)
+        return RaggedPlan(B, float(velocity), float(dt), final_wps, batch.row_offsets, batch.traj, batch.total_rows,
+                          batch.start_positions.contiguous(), converged)
+
+    def _plan_collision_free_host(self, waypoints, obstacles, velocity, dt, max_iterations, strict, recheck_passes) -> RaggedPlan:
+        """Round 2's loop: every round a ragged planning batch with rows, hit flags to the host, NumPy midpoint insertion."""
         torch = self._torch
         wps = [np.ascontiguousarray(w, dtype=np.float64) for w in waypoints]
         B = len(wps)
@@ -439,9 +524,18 @@ class Engine:
         so_host = np.zeros(B + 1, dtype=np.int64)
         np.cumsum(counts, out=so_host[1:])
         S = int(so_host[-1])
-        kw = dict(device=self.device)
         wp = self._dev(np.concatenate(wps, axis=0), torch.float64)
         so = self._dev(so_host, torch.int64)
+        batch = self._plan_ragged_tensors(wp, so, so_host, max_m, velocity, dt, cuboid)
+        if strict:
+            self.check(batch)
+        return batch
+
+    def _plan_ragged_tensors(self, wp, so, so_host, max_m: int, velocity: float, dt: float, cuboid) -> RaggedBatch:
+        """`plan_ragged` on device-resident waypoints wp (S + B, 3) / seg_offsets so (B + 1,) (so_host: the same on the host)."""
+        torch = self._torch
+        B, S = len(so_host) - 1, int(so_host[-1])
+        kw = dict(device=self.device)
         times = torch.empty((S,), dtype=torch.float64, **kw)
         seg_rows = torch.empty((S,), dtype=torch.int32, **kw)
         row_offsets = torch.empty((B + 1,), dtype=torch.int64, **kw)
@@ -460,11 +554,8 @@ class Engine:
         traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
         self.ctx.call("uavac_minsnap_sample_ragged_dev", _ptr(coeffs), _ptr(seg_rows), _ptr(so), _ptr(row_offsets), B, max_m,
                       S, float(dt), _ptr(traj), total, _ptr(aabb), _ptr(hit), _ptr(first_yaw))
-        batch = RaggedBatch(B, max_m, float(velocity), float(dt), so, so_host, wp, times, seg_rows, row_offsets, coeffs, status,
-                            traj, total, first_yaw, hit)
-        if strict:
-            self.check(batch)
-        return batch
+        return RaggedBatch(B, max_m, float(velocity), float(dt), so, so_host, wp, times, seg_rows, row_offsets, coeffs, status,
+                           traj, total, first_yaw, hit)
 
     def solve(self, plan: Plan):
         """Re-run times/row counts + coefficient solve into plan's buffers (no allocation, no sync)."""
