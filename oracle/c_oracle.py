@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle.so")
+# UAVAC_ORACLE_SO: another build of the same oracle (the sanitizer build of `make -C oracle asan`, tests/test_sanitizers.py)
+_SO = os.environ.get("UAVAC_ORACLE_SO") or os.path.join(_HERE, "_build", "liboracle.so")
 _P = C.c_void_p
 
 
