@@ -202,6 +202,38 @@ def launch_check(args):
         sys.exit(3)
 
 
+def yaw_fork_census(eng, n=1024):
+    """How often does the yaw column fork from NumPy's by a multiple of 2 pi?  Where the horizontal velocity reverses through
+    (almost) zero the heading steps by pi to the last bit, and whether np.unwrap then adds 2 pi hangs on the rounding of two
+    atan2 results -- the GPU's here, NumPy's in the reference.  Counted on `n` missions of the 8(d) distribution and
+    of the stress distribution U(1, 6) m: the NumPy oracle's yaw scan (np.arctan2 + np.unwrap, hold, back-fill) is run on the
+    GPU rows' OWN velocities, so any difference is the yaw step's alone.  Part of the checker leg (oracle import)."""
+    from oracle import minsnap_oracle as mo
+    out = {}
+    for name, lo, hi in (("8d_U(2.5,3.5)", 2.5, 3.5), ("stress_U(1,6)", 1.0, 6.0)):
+        rng = np.random.default_rng(20260807 + SEGMENTS)
+        d = rng.standard_normal((n, SEGMENTS, 3)) * np.array([1, 1, 0.25])
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        L = rng.uniform(lo, hi, (n, SEGMENTS, 1))
+        w0 = np.concatenate([rng.uniform(0, 24, (n, 1, 1)), rng.uniform(0, 14, (n, 1, 1)), np.full((n, 1, 1), -3.0)], axis=2)
+        wps = np.concatenate([w0, w0 + np.cumsum(L * d, axis=1)], axis=1)
+        plan = eng.plan(wps, VELOCITY, DT)
+        rows = plan.traj.cpu().numpy()
+        ro = plan.row_offsets.cpu().numpy()
+        forks = worst_other = 0
+        for b in range(n):
+            r = rows[ro[b]:ro[b + 1]]
+            ref = mo.yaws_from_velocity(r[:, 3:6])
+            diff = np.abs(r[:, 9] - ref)
+            turns = np.round(diff.max() / (2 * np.pi))
+            if turns >= 1:
+                forks += 1
+            else:
+                worst_other = max(worst_other, float(diff.max()))
+        out[name] = {"missions": n, "missions_2pi_apart_from_numpy": int(forks), "max_abs_diff_elsewhere_rad": worst_other}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -658,6 +690,7 @@ def main():
         out["gather_error"] = gather_err
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(eng, wps)
+        out["checks"]["yaw_2pi_forks"] = yaw_fork_census(eng)
     print(json.dumps(out), flush=True)
     leave()
 

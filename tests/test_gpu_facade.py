@@ -175,6 +175,29 @@ def test_trajectory_controller_open_loop_trace_matches_reference_golden(quad):
     tc.reset()                                                     # upstream test_main.py:13-34
     assert (tc.trajectory_index, tc.inner_step, tc.thrust_cmd, tc.controller.integral_error) == (0, 0, 0.0, 0)
     assert np.all(tc.pqr_cmd == 0)
+    # round-2 ADVICE: the reference reads self.trajectory[idx] live (main.py:48) -- an edit IN PLACE of a row that has not
+    # been consumed yet must reach the GPU: same trace as a controller built on the edited rows from the start
+    edited = g["traj"].copy()
+    edited[2:, 2] -= 0.7                                           # other altitude targets from the third row on
+    def trace(tc_, q_, n=30):
+        out = []
+        for _ in range(n):
+            tc_.step()
+            out.append(np.concatenate([[tc_.thrust_cmd], tc_.pqr_cmd, q_.omega_command, [tc_.trajectory_index]]))
+        return np.array(out)
+    import copy
+    q1, q2 = copy.deepcopy(quad), copy.deepcopy(quad)
+    for q_ in (q1, q2):
+        q_.X = g["X0"].copy()
+        q_.omega = np.full(4, np.sqrt(0.5 * 9.81 / 4))
+        q_.omega_command = np.zeros(4)
+    live = g["traj"].copy()
+    tc1 = TrajectoryController(CascadedController(9.81, 0.01), q1, live, 10)
+    head = trace(tc1, q1, 15)                                      # rows 0 and 1 consumed
+    live[2:, 2] -= 0.7                                             # in place: same object, same shape, same pointer
+    tail = trace(tc1, q1, 15)
+    tc2 = TrajectoryController(CascadedController(9.81, 0.01), q2, edited, 10)
+    assert np.array_equal(np.vstack([head, tail]), trace(tc2, q2, 30))
 
 
 def test_facade_closed_loop_matches_reference_golden(quad):

@@ -35,12 +35,20 @@ class TrajectoryController:
         self.pqr_cmd.fill(0.0)
 
     def _pilot(self) -> nat.Pilot:
-        """Resident session for this trajectory (`uavac_pilot_*`): the rows go to the GPU once, not once per tick."""
+        """Resident session for this trajectory (`uavac_pilot_*`): the rows go to the GPU once, not once per tick.
+        The reference reads `self.trajectory[self.trajectory_index]` live on every outer tick (main.py:48), so an edit in
+        place must not be missed: besides the identity of the object, the row an outer tick is about to consume is compared
+        with what was uploaded (11 doubles), and the rows are uploaded again when it differs."""
         traj = self.trajectory
-        key = (id(traj), getattr(traj, "shape", None), traj.ctypes.data if isinstance(traj, np.ndarray) else None)
-        if getattr(self, "_pilot_key", None) != key:
+        key = (id(traj), getattr(traj, "shape", None), traj.ctypes.data if isinstance(traj, np.ndarray) else None, len(traj))
+        stale = getattr(self, "_pilot_key", None) != key
+        if not stale and self.inner_step % max(int(self.inner_loop_frequency), 1) == 0 and len(traj):
+            i = min(max(int(self.trajectory_index), 0), len(traj) - 1)
+            stale = not np.array_equal(np.asarray(traj[i], dtype=np.float64), self._pilot_rows[i])
+        if stale:
             rows = nat.as_f64(traj)
             self._pilot_obj = nat.Pilot(ctx(), rows, np.array([0, len(rows)], dtype=np.int64))
+            self._pilot_rows = rows.copy()          # what the GPU holds
             self._pilot_key = key
         return self._pilot_obj
 
