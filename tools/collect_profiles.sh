@@ -1,8 +1,9 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, collected on the GPU box into gpurun_out/profiles_<tag>/ (copy what is to be
-# judged into profiles/ afterwards).   bash tools/collect_profiles.sh r02
+# judged into profiles/ afterwards).   bash tools/collect_profiles.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+export UAVAC_PROFILE_TAG=$TAG
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/profiles_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -13,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench --
 python3 tools/summarize_trace.py "$(ls $OUT/trace/*kernel_trace.csv | head -1)" "$OUT/${TAG}_bench" > "$OUT/per_dispatch_summary.txt"
 # 2. PMC traffic (three passes) -> hbm_traffic.json + pmc summary
 python3 tools/pmc_traffic.py > "$OUT/pmc_traffic.log" 2>&1
-cp gpurun_out/hbm_traffic.json "$OUT/hbm_traffic.json"; cp gpurun_out/r02_pmc_summary.csv "$OUT/${TAG}_pmc_summary.csv"
+cp gpurun_out/hbm_traffic.json "$OUT/hbm_traffic.json"; cp gpurun_out/${TAG}_pmc_summary.csv "$OUT/${TAG}_pmc_summary.csv"
 cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json      # so that the bench of step 3 quotes it
 # 3. the plain bench line (what the driver runs)
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
@@ -37,5 +38,9 @@ PY
 python3 tools/single_uav_loop.py 2>/dev/null | tail -4 > "$OUT/${TAG}_single_uav_loop.txt"
 python3 tools/host_path_rate.py 2>/dev/null | tail -2 > "$OUT/${TAG}_host_path_rate.txt"
 python3 tools/first_launch_bisect.py 2>/dev/null | grep "^|" > "$OUT/${TAG}_first_launch_bisect.md"
-rm -rf "$OUT/trace/"*results.db "$OUT/pmc_small"
+# 7. round 3: effective clock of the rollout by batch size, obstacle-loop rate
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_rclock" -o pmc -- python3 tools/rollout_clock.py > /dev/null 2>&1
+python3 tools/rollout_clock.py --report "$OUT/pmc_rclock" > "$OUT/${TAG}_rollout_clock.jsonl" 2>/dev/null
+python3 tools/replan_rate.py 4096 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_replan_rate.txt"
+rm -rf "$OUT/trace/"*results.db "$OUT/pmc_small" "$OUT/pmc_rclock"
 ls -la "$OUT"

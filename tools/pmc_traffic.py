@@ -27,12 +27,13 @@ sys.path.insert(0, ROOT)
 from bench import B_PER_GPU, CHUNK, F, rollout_source_sha  # noqa: E402
 
 OUT = os.path.join(ROOT, "gpurun_out")
+TAG = os.environ.get("UAVAC_PROFILE_TAG", "r03")          # round tag of the files written
 KERNELS = {"control_rollout": "control_rollout_kernel", "minsnap_sample": "minsnap_sample_kernel",
            "minsnap_solve": "minsnap_solve_bt_kernel"}
 
 
 def collect(counter):
-    d = os.path.join(OUT, f"pmc_r02_{counter}")
+    d = os.path.join(OUT, f"pmc_{TAG}_{counter}")
     subprocess.run(["rm", "-rf", d], check=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
@@ -86,10 +87,10 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
-    with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.csv"), "w", newline="") as fh:
+    with open(os.path.join(ROOT, "profiles", f"{TAG}_pmc_summary.csv"), "w", newline="") as fh:
         csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC).writerows(rows)
     # copies for the round trip through gpurun_out/ (profiles/ itself is not merged back from the GPU box)
-    subprocess.run(["cp", os.path.join(ROOT, "profiles", "hbm_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_summary.csv"), OUT])
+    subprocess.run(["cp", os.path.join(ROOT, "profiles", "hbm_traffic.json"), os.path.join(ROOT, "profiles", f"{TAG}_pmc_summary.csv"), OUT])
     print(json.dumps(rec, indent=1))
 
 
