@@ -481,8 +481,10 @@ def main():
     if not args.no_config4:
         del plan, fleet, log
         torch.cuda.empty_cache()
-        B4 = C4_TOTAL // world
-        wps4 = missions(C4_TOTAL, C4_SEGMENTS, rank * B4, (rank + 1) * B4)
+        from uav_ac.fleet import shard_bounds
+        lo4, hi4 = shard_bounds(C4_TOTAL, rank, world)          # contiguous blocks; any N (sizes differ by at most one)
+        B4 = hi4 - lo4
+        wps4 = missions(C4_TOTAL, C4_SEGMENTS, lo4, hi4)
         plan4 = eng.plan(wps4, VELOCITY, DT)
         fleet4 = eng.fleet(plan4)
         log4 = torch.empty((CHUNK, 13, B4), dtype=torch.float64, device=dev)
@@ -576,7 +578,8 @@ def main():
                     ok = sum(counts) == gathered.shape[0] and bool((gathered[:own] == plan4.traj[:own]).all())
                     # every peer's block starts with its first mission's first waypoint, at rest
                     offs = np.concatenate([[0], np.cumsum(counts)])
-                    first = missions(C4_TOTAL, C4_SEGMENTS, 0, C4_TOTAL)[::B4, 0, :]
+                    starts = [shard_bounds(C4_TOTAL, r, world)[0] for r in range(world)]
+                    first = missions(C4_TOTAL, C4_SEGMENTS, 0, C4_TOTAL)[starts, 0, :]
                     got = gathered[torch.as_tensor(offs[:-1], device=dev), 0:3].cpu().numpy()
                     ok = ok and bool(np.array_equal(got, first))
                     if not ok:
@@ -609,7 +612,7 @@ def main():
                     if not same:
                         gather_err = gather_err or "rows re-sampled from the gathered plan differ from the gathered rows"
                     c4["plan_gather_verified"] = bool(same)
-                    c4["plan_gather_bytes_into_root"] = int((C4_TOTAL - B4) * C4_SEGMENTS * 204)
+                    c4["plan_gather_bytes_into_root"] = int((C4_TOTAL - B4) * C4_SEGMENTS * 204)        # coefficients 192 + duration 8 + rows 4
                 del gathered, gp
                 plan_s = timed(lambda: holder.append(plan_gather()) or holder.clear(), 2)
                 if rank == 0:
