@@ -193,6 +193,9 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
  * peers' plans after uavac_gather_plan_dev): exclusive prefix sum of the per-mission totals
  * (sum of len(np.arange(0, T, dt)) over the mission's splines, minimum_snap.py:104). */
 int uavac_minsnap_row_offsets_dev(uavac_ctx *ctx, const int32_t *seg_rows, int B, int m, int64_t *row_offsets);
+/* The same for a ragged batch (seg_rows [S] back to back, mission b's at seg_offsets[b] .. seg_offsets[b+1]). */
+int uavac_minsnap_row_offsets_ragged_dev(uavac_ctx *ctx, const int32_t *seg_rows, const int64_t *seg_offsets, int B,
+                                         int max_m, int64_t *row_offsets);
 
 /* Ragged batches: missions with different numbers of waypoints in one call -- what a fleet of MinimumSnap objects with
  * paths of different lengths is (minimum_snap.py:13-57 takes any path), and what the obstacle loop (:63-95) produces as

@@ -55,6 +55,7 @@ int main(void) {
     EXPECT(uavac_minsnap_sample_derivs_dev(NULL, d, i32, i64, 1, 1, 0.01, d, d, d, d, d) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_plan_dev(NULL, d, 1, 1, 1.0, 0.01, d, i32, i64, d, i32, d, 1, d, d) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_row_offsets_dev(NULL, i32, 1, 1, i64) == UAVAC_EINVAL);
+    EXPECT(uavac_minsnap_row_offsets_ragged_dev(NULL, i32, i64, 1, 1, i64) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_plan_ragged(NULL, d, i64, 1, 1.0, 0.01, d, i64, d, d, 0) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_row_counts_ragged_dev(NULL, d, i64, 1, 1, 1.0, 0.01, d, i32, i64) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_solve_ragged_dev(NULL, d, d, i64, 1, 1, d, i32) == UAVAC_EINVAL);
@@ -99,6 +100,6 @@ int main(void) {
     EXPECT(uavac_gather_rows_dev(NULL, NULL, d, 1, 11, i64, 0, d) == UAVAC_EINVAL);
     EXPECT(uavac_gather_plan_dev(NULL, NULL, d, d, i32, 1, i64, 0, d, d, i32) == UAVAC_EINVAL);
     EXPECT(uavac_comm_finish(NULL, NULL) == UAVAC_EINVAL && uavac_comm_loopback_dev(NULL, NULL, d, d, 1) == UAVAC_EINVAL);
-    printf("asan driver: %d entry points answered a GPU-less host as documented\n", 70);
+    printf("asan driver: %d entry points answered a GPU-less host as documented\n", 71);
     return 0;
 }

@@ -329,3 +329,41 @@ def test_yaw_column_never_forks_from_numpy_on_the_baseline_distribution(eng):
             r = rows[ro[b]:ro[b + 1]]
             worst = max(worst, float(np.abs(r[:, 9] - mo.yaws_from_velocity(r[:, 3:6])).max()))
         assert worst < 1e-9, (lo, hi, worst)
+
+
+def test_ragged_plan_gather_world1_and_plan_fed_flight_of_an_obstacle_corrected_plan(eng, nat):
+    """The plan gather for ragged batches (what the obstacle loop produces): splines per mission travel as one more column,
+    the root re-samples with the ragged sampler -- rows bit-identical to the row gather.  And the RaggedPlan of
+    plan_collision_free now carries its coefficients: a Fleet flies it from them exactly as from its rows."""
+    import torch
+    from uav_ac.fleet import RcclComm
+    lab = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0],
+                    [13.3, 14.7, 6.3, 7.7, -6.0, 0.0], [20.2, 20.8, 4.0, 10.0, -3.3, -2.7]])
+    wps = _missions(900, 8)
+    ragged = [w[:n] for w, n in zip(wps, np.random.default_rng(11).integers(2, 10, len(wps)))]
+    rp = eng.plan_collision_free(ragged, lab, 3.0, 0.01, strict=False, max_iterations=10)
+    assert rp.batch is not None and rp.coeffs.shape[0] == int(rp.seg_offsets_host[-1])
+    buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+    eng.ctx.call("uavac_comm_unique_id", buf)
+    comm = RcclComm(eng, unique_id=bytes(buf.raw), world=1, rank=0)
+    try:
+        rows, counts = comm.gather_rows(rp.traj, dst=0)
+        for plan in (rp, rp.batch):
+            gp, pcounts = comm.gather_plan(plan, dst=0)
+            assert pcounts == counts and torch.equal(gp.traj, rows)
+            assert torch.equal(gp.seg_offsets, rp.seg_offsets) and torch.equal(gp.coeffs, rp.coeffs)
+            assert torch.equal(gp.row_offsets, rp.row_offsets) and torch.equal(gp.first_yaw, rp.first_yaw)
+            assert torch.equal(gp.start_positions, rp.start_positions)
+    finally:
+        comm.close()
+    flights = []
+    for feed in (False, True):
+        f = eng.fleet(rp, from_plan=feed)
+        log, _ = f.rollout(900, state_log=True)
+        flights.append((log, f.state[:26].clone(), f.istate.clone()))
+    for a, b in zip(*flights):
+        assert torch.equal(a, b)
+    # the gathered batch flies too (its start positions come from the coefficients)
+    f = eng.fleet(gp, from_plan=True)
+    log, _ = f.rollout(900, state_log=True)
+    assert torch.equal(log, flights[0][0])

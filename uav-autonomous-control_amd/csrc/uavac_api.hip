@@ -508,6 +508,14 @@ int uavac_minsnap_row_offsets_dev(uavac_ctx *ctx, const int32_t *seg_rows, int B
     return uavac_launch_row_offsets(ctx, seg_rows, B, m, row_offsets);
 }
 
+int uavac_minsnap_row_offsets_ragged_dev(uavac_ctx *ctx, const int32_t *seg_rows, const int64_t *seg_offsets, int B, int max_m,
+                                         int64_t *row_offsets) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_plan_args(ctx, seg_rows, B, max_m)) return rc;
+    if (!seg_offsets || !row_offsets) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    return uavac_launch_row_offsets(ctx, seg_rows, B, max_m, row_offsets, seg_offsets);
+}
+
 int uavac_minsnap_obstacle_round_dev(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, int max_m,
                                      double velocity, double dt, const double *aabb, int32_t *active, int32_t *overflow,
                                      int32_t *touched, double *wp_out, int64_t *seg_offsets_out, int32_t *counters,

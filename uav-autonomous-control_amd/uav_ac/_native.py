@@ -77,6 +77,7 @@ _SIGNATURES = {
     "uavac_minsnap_plan_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P, _P,
                                           C.c_int64, _P, _P]),
     "uavac_minsnap_row_offsets_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "uavac_minsnap_row_offsets_ragged_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "uavac_minsnap_plan_ragged": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, C.c_int64]),
     "uavac_minsnap_row_counts_ragged_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),
     "uavac_minsnap_solve_ragged_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),

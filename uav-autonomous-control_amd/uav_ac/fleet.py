@@ -73,10 +73,19 @@ class RaggedPlan:
     total_rows: int
     start_positions: "object"        # (B, 3) f64
     converged: "object" = None       # (B,) bool, host: False where the bounded obstacle loop gave up
+    batch: "object" = None           # the RaggedBatch the rows were sampled from (coefficients, rows per spline, first headings):
+                                     # lets a Fleet fly the plan from its coefficients and RcclComm.gather_plan ship it
 
     def mission(self, b: int) -> np.ndarray:
         ro = self.row_offsets[b:b + 2].cpu().numpy()
         return self.traj[int(ro[0]):int(ro[1])].cpu().numpy().copy()
+
+    def __getattr__(self, name):     # coeffs, seg_rows, seg_offsets, first_yaw, max_m, times ...: the batch's, when there is one
+        batch = self.__dict__.get("batch")
+        if batch is not None and name in ("coeffs", "seg_rows", "seg_offsets", "seg_offsets_host", "first_yaw", "max_m", "times",
+                                          "waypoints", "status"):
+            return getattr(batch, name)
+        raise AttributeError(name)
 
 
 @dataclass
@@ -108,6 +117,8 @@ class RaggedBatch:
     def start_positions(self):
         """(B, 3): first waypoint of every mission (what `Fleet` starts its vehicles from)."""
         import torch
+        if self.waypoints is None:                  # assembled from gathered parts: c0 of a mission's first spline IS its first waypoint
+            return self.coeffs[self.seg_offsets[:-1], 0, :]
         first = self.seg_offsets[:-1] + torch.arange(self.B, dtype=self.seg_offsets.dtype, device=self.seg_offsets.device)
         return self.waypoints[first]
 
@@ -279,6 +290,36 @@ class Engine:
         self.sample(plan)
         return plan
 
+    def ragged_from_parts(self, coeffs, times, seg_rows, seg_counts, velocity: float, dt: float, total_rows: int = None,
+                          traj=None) -> RaggedBatch:
+        """`plan_from_parts` for a ragged batch: coefficients (S, 8, 3), durations (S,) or None, rows per spline (S,) back to back
+        and the number of splines of every mission (B,) -> RaggedBatch with the rows re-sampled (bit-identical)."""
+        torch = self._torch
+        co = self._dev(coeffs, torch.float64).reshape(-1, 8, 3)
+        sr = self._dev(seg_rows, torch.int32).reshape(-1)
+        cnt = np.asarray(seg_counts.cpu() if hasattr(seg_counts, "cpu") else seg_counts, dtype=np.int64).reshape(-1)
+        B, S = len(cnt), int(cnt.sum())
+        if S != co.shape[0] or S != sr.shape[0] or B < 1 or cnt.min() < 1 or cnt.max() > nat.MAX_SEGMENTS:
+            raise ValueError("segment counts, coefficients and row counts disagree")
+        so_host = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(cnt, out=so_host[1:])
+        so = self._dev(so_host, torch.int64)
+        max_m = int(cnt.max())
+        kw = dict(device=self.device)
+        row_offsets = torch.empty((B + 1,), dtype=torch.int64, **kw)
+        self._bind_stream()
+        self.ctx.call("uavac_minsnap_row_offsets_ragged_dev", _ptr(sr), _ptr(so), B, max_m, _ptr(row_offsets))
+        total = int(row_offsets[-1].item()) if total_rows is None else int(total_rows)
+        if traj is None:
+            traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
+        first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
+        self.ctx.call("uavac_minsnap_sample_ragged_dev", _ptr(co), _ptr(sr), _ptr(so), _ptr(row_offsets), B, max_m, S, float(dt),
+                      _ptr(traj), int(traj.shape[0]), None, None, _ptr(first_yaw))
+        tm = None if times is None else self._dev(times, torch.float64).reshape(-1)
+        # the first waypoint of every mission is c0 of its first spline; the others are not needed to fly or to ship the plan
+        return RaggedBatch(B, max_m, float(velocity), float(dt), so, so_host, None, tm, sr, row_offsets, co,
+                           torch.zeros((B,), dtype=torch.int32, **kw), traj[:total], total, first_yaw, None)
+
     def take_flags(self):
         """Synchronise and return-and-clear the sticky device-side flags of the `_dev` planning entry points:
         [non-finite duration, singular system, trajectory buffer too small, mission longer than 2^31-1 rows]."""
@@ -416,7 +457,7 @@ class Engine:
         final_wps = [wp_host[so_final[b] + b:so_final[b + 1] + b + 1].copy() for b in range(B)]
         converged = ~failed.cpu().numpy().astype(bool)
         return RaggedPlan(B, float(velocity), float(dt), final_wps, batch.row_offsets, batch.traj, batch.total_rows,
-                          batch.start_positions.contiguous(), converged)
+                          batch.start_positions.contiguous(), converged, batch)
 
     def _plan_collision_free_host(self, waypoints, obstacles, velocity, dt, max_iterations, strict, recheck_passes) -> RaggedPlan:
         """Round 2's loop: every round a ragged planning batch with rows, hit flags to the host, NumPy midpoint insertion."""
@@ -896,7 +937,9 @@ class RcclComm:
     def gather_plan(self, plan: Plan, dst: int = 0, traj=None):
         """The final gather as a gather of the PLAN: every rank sends the coefficients, durations and per-spline row
         counts of its missions (204 B per spline; ~10 KB of rows per spline stay where they are), and `dst` re-samples
-        them with the very kernel the peers ran -> (Plan of all missions on dst | None, row counts per rank).
+        them with the very kernel the peers ran -> (Plan of all missions on dst | None, row counts per rank).  A ragged
+        batch (`RaggedBatch`, or the `RaggedPlan` of `plan_collision_free`) travels the same way, with the number of splines
+        of every mission as one more column, and comes back as a RaggedBatch.
         `gathered.traj` equals what `gather_rows(plan.traj)` delivers, bit for bit.  Synchronous."""
         return self.gather_finish(self.gather_plan_begin(plan, dst, traj=traj))
 
@@ -904,32 +947,50 @@ class RcclComm:
         """Enqueue `gather_plan` and return at once (`stream`, ticket: as for `gather_rows_begin`; the root's re-sampling
         is enqueued on that stream too, behind the receives).  `traj`: a preallocated row buffer for the root."""
         e, torch = self.engine, self.engine._torch
-        if not hasattr(plan, "m") or getattr(plan, "coeffs", None) is None or not plan.coeffs.is_cuda:
-            raise ValueError("gather_plan takes a device-resident Plan (one segment count per batch)")
-        m = int(plan.m)
+        if getattr(plan, "coeffs", None) is None or not plan.coeffs.is_cuda:
+            raise ValueError("gather_plan takes a device-resident Plan, RaggedBatch or RaggedPlan with its batch")
+        ragged = not hasattr(plan, "m")
+        if ragged and getattr(plan, "seg_offsets", None) is None:
+            raise ValueError("this plan has neither one segment count for the batch nor seg_offsets")
+        m = 0 if ragged else int(plan.m)
+        n_seg = int(plan.seg_offsets_host[-1]) if ragged else plan.B * m
         here = torch.cuda.current_stream(e.device)
         stream = here if stream is None else stream
         if stream is not here:
             stream.wait_stream(here)
         with torch.cuda.stream(stream):
-            seg_counts = self.counts(plan.B * m)             # two tiny synchronous all-gathers on that stream
+            seg_counts = self.counts(n_seg)                  # tiny synchronous all-gathers on that stream
             row_counts = self.counts(plan.total_rows)
-            if any(c % m for c in seg_counts):
+            kw = dict(device=e.device)
+            per_mission = b_counts = None
+            if ragged:
+                # splines per mission travel as one more (exact) f64 column through the row gather
+                b_counts = self.counts(plan.B)
+                mine = (plan.seg_offsets[1:] - plan.seg_offsets[:-1]).to(torch.float64).reshape(-1, 1).contiguous()
+                per_mission = torch.empty((sum(b_counts), 1), dtype=torch.float64, **kw) if self.rank == dst else None
+                e._bind_stream()
+                e.ctx.call("uavac_gather_rows_dev", self._h, _ptr(mine), plan.B, 1, (C.c_int64 * self.world)(*b_counts), int(dst),
+                           _ptr(per_mission))
+            elif any(c % m for c in seg_counts):
                 raise ValueError(f"every rank must plan with the same segment count (m = {m} here)")
             gathered = keep = None
             S = sum(seg_counts)
             co = tm = sr = None
+            times = getattr(plan, "times", None)
             if self.rank == dst:
-                kw = dict(device=e.device)
-                co = torch.empty((S // m, 8 * m, 3), dtype=torch.float64, **kw)
-                tm = torch.empty((S // m, m), dtype=torch.float64, **kw) if plan.times is not None else None
-                sr = torch.empty((S // m, m), dtype=torch.int32, **kw)
+                co = torch.empty((S, 8, 3), dtype=torch.float64, **kw)
+                tm = torch.empty((S,), dtype=torch.float64, **kw) if times is not None else None
+                sr = torch.empty((S,), dtype=torch.int32, **kw)
             e._bind_stream()
-            e.ctx.call("uavac_gather_plan_dev", self._h, _ptr(plan.coeffs), _ptr(plan.times), _ptr(plan.seg_rows), plan.B * m,
+            e.ctx.call("uavac_gather_plan_dev", self._h, _ptr(plan.coeffs), _ptr(times), _ptr(plan.seg_rows), n_seg,
                        (C.c_int64 * self.world)(*seg_counts), int(dst), _ptr(co), _ptr(tm), _ptr(sr))
             if self.rank == dst:
-                gathered = e.plan_from_parts(co, tm, sr, m, plan.velocity, plan.dt, total_rows=sum(row_counts), traj=traj)
-            keep = plan
+                if ragged:
+                    gathered = e.ragged_from_parts(co, tm, sr, per_mission.reshape(-1).round().to(torch.int64), plan.velocity, plan.dt,
+                                                   total_rows=sum(row_counts), traj=traj)
+                else:
+                    gathered = e.plan_from_parts(co, tm, sr, m, plan.velocity, plan.dt, total_rows=sum(row_counts), traj=traj)
+            keep = (plan, per_mission)
         return (stream, gathered, row_counts, keep)
 
     def gather_finish(self, ticket):
