@@ -542,8 +542,13 @@ def test_fleet_picks_the_rollout_feed_by_batch_size(eng):
     assert big.from_plan is True
     ragged = eng.plan_collision_free([mo.synthetic_missions(1, 3)[0]], None, 3.0, 0.01)
     assert eng.fleet(ragged).from_plan is False
+    # since round 3 an obstacle-corrected plan carries its coefficients and may be flown from them; the rows-only plan of the
+    # host-side loop (kept for comparison) cannot
+    assert eng.fleet(ragged, from_plan=True).from_plan is True
+    rows_only = eng.plan_collision_free([mo.synthetic_missions(1, 3)[0]], np.array([[50.0, 51, 50, 51, -1, 0]]), 3.0, 0.01,
+                                        device_loop=False)
     with pytest.raises(ValueError):
-        eng.fleet(ragged, from_plan=True)
+        eng.fleet(rows_only, from_plan=True)
 
 
 @pytest.mark.parametrize("m,velocity,dt,F", [(64, 6.0, 0.05, 3), (20, 3.0, 0.01, 10), (5, 30.0, 0.05, 1), (2, 0.7, 0.02, 7)])

@@ -538,7 +538,8 @@ __global__ void __launch_bounds__(256) rollout_align_kernel() {}
 // per CU once the yaw tile is gone -- is bit-identical and changes nothing: 14.46-14.49 ms per bench step against
 // 14.49-14.54 (a throw-away probe on the round-2 tree).  The rendezvous is not what couples the stages.)  (Four compute + four store waves per 256 UAVs -- one workgroup per CU, whose
 // 8 waves the dispatcher always deals round the 4 SIMDs evenly, so that no aligner is needed -- was measured at 1.65 ms
-// per 1 000 ticks against 1.33 ms: the per-tick barrier then couples eight waves.  The kernel keeps its CW / SW
+// per 1 000 ticks against 1.33 ms: the per-tick barrier then couples eight waves; round 3 measured two + two waves per 128 UAVs
+// slower at every batch size as well, profiles/r03_rollout_shapes_wide_workgroup.jsonl.  The kernel keeps its CW / SW
 // parameters; only <1, 1> is instantiated.)
 template <bool LS, bool LC, bool AB, bool POLY, bool GR, bool YS>
 void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
@@ -549,15 +550,15 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     constexpr bool LOGGING = LS || LC || WATCH;
     constexpr int NU = 64 * CW;
     constexpr int NR = (LS ? 13 : 0) + (LC ? UAVAC_CMD_COLS : 0) + (WATCH ? 3 : 0);
-    const int n_tiles_ = (B + NU - 1) / NU;
-    constexpr int nsw = 1;
-    // a placeholder wave between compute and store wave where two workgroups share a CU (257 .. 512 tiles on 1 024 SIMDs)
+    const int n_tiles = (B + NU - 1) / NU;
+    // a placeholder wave between compute and store wave where two workgroups share a CU (more than a quarter, at most half
+    // as many tiles as the chip has SIMDs: 257 .. 512 on an MI355X) -- see the kernel, PLACEHOLDER WAVES
     int n_idle = 0;
     if (LOGGING) {
         if (ctx->idle_waves >= 0) n_idle = ctx->idle_waves > 1 ? 1 : ctx->idle_waves;
-        else n_idle = (4 * n_tiles_ > ctx->n_simds && 2 * n_tiles_ <= ctx->n_simds) ? 1 : 0;
+        else n_idle = (4 * n_tiles > ctx->n_simds && 2 * n_tiles <= ctx->n_simds) ? 1 : 0;
     }
-    const int threads = NU + (LOGGING ? 64 * (nsw + n_idle) : 0);
+    const int threads = NU + (LOGGING ? 64 * (1 + n_idle) : 0);
     const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0));
     auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS>;
     if (lds + (size_t)ctx->lds_pad > 64 * 1024)
@@ -568,14 +569,15 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     // at 4.04 ms per 1 000 ticks for B = 131 072 against 3.15 ms for two launches): every launch boundary made all SIMDs
     // wait for the slowest one.  Without a second wave one launch of all tiles is kept (two compute waves per SIMD hide
     // each other's latency).  Results do not depend on the split.
-    const int n_tiles = (B + NU - 1) / NU;
     const int max_wgs = ctx->n_simds / CW;                     // one compute wave per SIMD at most
     const int grid = (LOGGING && n_tiles > max_wgs) ? max_wgs : n_tiles;
     const int cols = grid * NU < B ? grid * NU : B;            // columns in flight at a time
     // Hand the slab over at the end of the tick, or a third of a tick later (after the next tick's motor model)?  Results
     // are the same bit for bit; per 1 000 logged ticks, end-of-tick / late: 0.905 / 0.880 ms at 8 192 and 16 384 columns,
-    // 0.979 / 0.985 at 24 576, 0.996 / 1.044 at 32 768, 1.16 / 1.11-1.14 at 49 152, 1.33 / 1.30 at 65 536.
-    const int late = ctx->late_handover >= 0 ? ctx->late_handover : ((cols > 20480 && cols < 40960) ? 0 : 1);
+    // 0.979 / 0.985 at 24 576, 0.996 / 1.044 at 32 768, 1.16 / 1.11-1.14 at 49 152, 1.33 / 1.30 at 65 536 (MI355X: 1 024 SIMDs;
+    // the thresholds scale with the SIMD count of the device).
+    const int late = ctx->late_handover >= 0 ? ctx->late_handover
+                                             : ((cols > 20 * ctx->n_simds && cols < 40 * ctx->n_simds) ? 0 : 1);
     const size_t pitch = (LS || LC) ? (ctx->log_pitch > 0 ? (size_t)ctx->log_pitch : (size_t)B) : (size_t)B;
     if (LOGGING && ctx->rollout_align)
         hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(threads), 0, ctx->stream);
