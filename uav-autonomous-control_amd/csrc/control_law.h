@@ -170,10 +170,20 @@ __device__ __forceinline__ void body_rate(const VehK &V, double pc, double qc, d
     Mz = fma(V.ikp[2], rc - wr, fma(wp, Iwy, -(wq * Iwx)));
 }
 
-// Quad._allocate_rotor_forces (quad.py:105-122); rotor order FL, FR, RR, RL (quad.py:157-166)
-__device__ __forceinline__ void allocate(const VehK &V, double thrust, double Mx, double My, double Mz,
-                                         double f[4]) {
-    const double col = clampd(thrust, V.c_min, V.c_max) * 0.25;
+// Quad._allocate_rotor_forces (quad.py:105-122); rotor order FL, FR, RR, RL (quad.py:157-166).
+// The part that depends on the collective thrust command alone -- col = clip(c, 4 min, 4 max) / 4 and the head-room to the
+// rotor limits on either side -- changes only when an OUTER tick writes a new command: the rollout computes it there and
+// keeps it across the inner ticks in between (same operations on the same values: same bits as computing it every tick).
+struct Collective { double col, up, dn; };
+__device__ __forceinline__ Collective collective_of(const VehK &V, double thrust) {
+    Collective c;
+    c.col = clampd(thrust, V.c_min, V.c_max) * 0.25;
+    c.up = V.max_thrust - c.col;                                               // both >= 0
+    c.dn = c.col - V.min_thrust;
+    return c;
+}
+__device__ __forceinline__ void allocate(const VehK &V, const Collective &c, double Mx, double My, double Mz, double f[4]) {
+    const double col = c.col;
     const double pb = Mx * V.inv_arm, qb = My * V.inv_arm, rb = -Mz * V.inv_kappa;
     double mf[4];
     mf[0] = (pb + qb + rb) * 0.25;
@@ -184,7 +194,7 @@ __device__ __forceinline__ void allocate(const VehK &V, double thrust, double Mx
     // mf_i < 0, 1 for mf_i == 0.  Both numerators are rotor independent, so the smallest limit on each side
     // belongs to the largest |mf_i| of that sign; the two candidates are compared by cross-multiplication
     // and only the winner is divided.  (The mf_i sum to zero: either both signs occur or all are zero.)
-    const double up = V.max_thrust - col, dn = col - V.min_thrust;            // both >= 0
+    const double up = c.up, dn = c.dn;
     const double mpos = fmax(fmax(mf[0], mf[1]), fmax(mf[2], mf[3]));          // >= 0
     const double mneg = -fmin(fmin(mf[0], mf[1]), fmin(mf[2], mf[3]));         // >= 0
     const bool pos_wins = up * mneg < dn * mpos;                               // up/mpos < dn/mneg
@@ -192,6 +202,10 @@ __device__ __forceinline__ void allocate(const VehK &V, double thrust, double Mx
     const double sc = (na < nb) ? na * fast_rcp(nb) : 1.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = clampd(fma(sc, mf[i], col), V.min_thrust, V.max_thrust);
+}
+__device__ __forceinline__ void allocate(const VehK &V, double thrust, double Mx, double My, double Mz,
+                                         double f[4]) {
+    allocate(V, collective_of(V, thrust), Mx, My, Mz, f);
 }
 
 // Quad.set_propeller_speed (quad.py:88-103): omega_cmd = sqrt(f/kf), first-order lag (rise / fall)

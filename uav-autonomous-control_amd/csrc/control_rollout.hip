@@ -263,12 +263,18 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     VehK L = V;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { L.I[i] = vk(V.I[i]); L.inv_I[i] = vk(V.inv_I[i]); L.ikp[i] = vk(V.ikp[i]); }
+    L.inv_mass = vk(V.inv_mass);     // (shares its 8-dword kernel-argument group with I[]: left in scalar registers, the whole
+                                     // group was spilled and restored with eight v_readlane on every tick)
     L.arm = vk(V.arm); L.inv_arm = vk(V.inv_arm); L.kappa = vk(V.kappa); L.inv_kappa = vk(V.inv_kappa);
     L.kf = vk(V.kf); L.inv_kf = vk(V.inv_kf);
     L.lit_tiny = vk(V.lit_tiny); L.lit_h2_small = vk(V.lit_h2_small); L.lit_c8 = vk(V.lit_c8); L.lit_c6 = vk(V.lit_c6);
     L.lit_c4 = vk(V.lit_c4); L.lit_s9 = vk(V.lit_s9); L.lit_s7 = vk(V.lit_s7); L.lit_s5 = vk(V.lit_s5); L.lit_s3 = vk(V.lit_s3);
     L.lit_375 = vk(V.lit_375); L.lit_e_small = vk(V.lit_e_small);
-
+    // The plan's sample period, used once per OUTER tick: in a vector register too in the kernels that log.  Left in scalar
+    // registers it costs four v_readlane per outer tick -- and the bench launch shape 2.6 % at B = 4 096 (0.853 against 0.831
+    // ms per 1 000 ticks, A/B in one process, tools/rollout_ab.py).  The kernels without a second wave keep it scalar: they
+    // sit at the 256-register limit of two waves per SIMD (tests/test_abi_and_host.py checks that budget).
+    const double plan_dt = !POLY ? 0.0 : (LOGGING ? vk(P.dt) : P.dt);
   for (int tile0 = 0; tile0 < n_tiles; tile0 += grid, kk += K) {
     const int n_here = min(grid, n_tiles - tile0);
     if ((int)blockIdx.x >= n_here) break;
@@ -357,7 +363,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 for (int row = 0; row < idx; ++row) {
                     while (r_ >= n_ && s_ + 1 < pm) { r_ -= n_; ++s_; n_ = seg_rows[s_]; load_coeffs(s_); }
                     double x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_;
-                    minsnap_eval_row<64>(cf, (double)r_ * P.dt, x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_);
+                    minsnap_eval_row<64>(cf, (double)r_ * plan_dt, x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_);
                     if (uavac_yaw::has_heading(vx_, vy_)) {
                         const double a_ = atan2(vy_, vx_);
                         if (yhas) ysum = ysum + uavac_yaw::unwrap_correction(a_ - yprev);
@@ -389,7 +395,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             // ------------------------------------------------------------- outer loop (main.py:47-61)
             double tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az, tg_yaw;
             if (POLY) {
-                minsnap_eval_row<64>(cf, (double)rin * P.dt, tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az);
+                minsnap_eval_row<64>(cf, (double)rin * plan_dt, tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az);
                 if (YAWSCAN) {
                     // this row's yaw from the carried scan (minimum_snap.py:126-136); committed below only if the cursor moves on
                     const bool yvalid = uavac_yaw::has_heading(tg_vx, tg_vy);
