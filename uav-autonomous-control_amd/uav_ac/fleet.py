@@ -151,6 +151,7 @@ class RRTDeviceBatch:
 
 class Engine:
     """One GPU, one `uavac_ctx`.  Kernels are enqueued on torch's current stream for that device."""
+    FAST_ROW_BUFFER_BYTES_PER_S = 5.6e12       # `place_rows`: a row buffer the sampler fills at this rate is of the fast kind
 
     def __init__(self, device=None):
         torch = _torch()
@@ -189,8 +190,8 @@ class Engine:
         `placement_trials` > 1: where the row buffer lies in HBM decides whether the sampler streams into it at ~6.0 or at
         ~5.1 TB/s -- a property of the allocation that lasts as long as the buffer (tools/buffer_placement_probe.py, DESIGN
         K2).  So allocate up to that many candidate buffers one after the other, time the sampler on each, stop at the first
-        one of the fast group (7 % below the slowest seen), keep the fastest and free the others (`plan.placement_ms` holds
-        the times).  For plans that are re-sampled many times (`replan`)."""
+        one the rows stream into at >= 5.6 TB/s (the fast kind), keep the fastest and free the others (`plan.placement_ms`
+        holds the times).  Optional, for plans that are re-sampled many times (`replan`); the default takes the first allocation."""
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -238,9 +239,13 @@ class Engine:
         for _ in range(8):                                       # clocks up before anything is compared
             self.sample(plan)
         # all candidates stay alive side by side until the choice is made (a freed block would come straight back from
-        # the allocator); the times fall into two groups ~15 % apart: stop at the first candidate of the fast group
+        # the allocator).  The times fall into groups (on one box 1.25 / 1.51 / 1.67 ms for 7.5 GB of rows): stop at the
+        # first candidate the rows stream into at >= 5.6 TB/s -- the fast group -- and otherwise keep the fastest of all.
+        # (Round 2 stopped at "7 % below the slowest seen", which a still slower outlier satisfied for a slow buffer.)
+        row_bytes = float(plan.total_rows) * nat.TRAJ_COLS * 8.0
+        fast_ms = row_bytes / self.FAST_ROW_BUFFER_BYTES_PER_S * 1e3
         candidates, times = [plan.traj], [timed(plan.traj)]
-        while len(candidates) < trials and not (len(times) > 1 and min(times) < 0.93 * max(times)):
+        while len(candidates) < trials and min(times) > fast_ms:
             try:
                 candidates.append(torch.empty_like(candidates[0]))
             except RuntimeError:                                 # out of memory: choose among what there is
