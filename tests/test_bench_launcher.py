@@ -63,3 +63,20 @@ def test_rehearsal_ranks_through_the_self_launcher_plan_gather_equals_row_gather
     c4 = line["config4"]
     assert c4["batch_per_gpu"] == -(-262144 // n) and c4["gather_verified"] is True and c4["plan_gather_verified"] is True   # 3 ranks: 87382 + 2 x 87381
     assert c4["plan_gather_ms"] > 0 and c4["steps_per_s_with_plan_gather"] > 0
+
+
+@pytest.mark.gpu
+def test_two_real_gpus_over_rccl_when_the_box_has_them():
+    """First contact with a real peer (round-2 ADVICE): on a box with >= 2 GPUs the self-launcher starts two ranks, one per GPU,
+    over RCCL; both gathers of the config-4 leg are verified on rank 0 (the re-sampled plan equals the gathered rows bit for
+    bit) and the overlapped variants run.  Skipped on the 1-GPU boxes of this pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"])
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "REHEARSAL" not in line and "gather_error" not in line
+    c4 = line["config4"]
+    assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True and "overlap_error" not in c4
+    assert c4["plan_overlapped_verified"] is True and c4["overlapped_verified"] is True
