@@ -110,6 +110,10 @@ const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
  * many 64-row chunks of the sampler's dense yaw column are written together.  "late_handover": -1
  * (default: chosen per launch), 0, 1 = when the compute wave hands a tick's log values to the store
  * wave.  "lds_pad": extra LDS bytes per rollout workgroup (caps the workgroups a CU takes; 0).
+ * "idle_waves": -1 (default: chosen per launch), 0, 1 = a placeholder wave between the compute and the
+ * store wave of every rollout workgroup, which lets two workgroups on a CU occupy all four SIMDs
+ * (16 385 .. 32 768 UAVs).  "sampler_waves": 1 (default), 4, 8, 16 = wavefronts per mission of the
+ * plain sampler (the multi-wave kernel is bit-identical and slower; kept for comparison).
  * Defaults from the environment (UAVAC_ROLLOUT_ALIGN, UAVAC_YAW_GROUP) at uavac_create.
  * ONE option is not a tuning knob but part of the log layout: "log_pitch" = P doubles per log row,
  * 0 (default) = B.  With P >= B the rollouts write state_log [K][13][P] and cmd_log [K][12][P]
