@@ -293,7 +293,7 @@ def main():
     # The row buffer is chosen among PLACEMENT_TRIALS allocations by timing the sampler on each (Engine.plan, DESIGN K2: whether
     # the rows stream out at ~6.0 or ~5.1 TB/s is a property of where the buffer lies, for as long as it lives).  Untimed
     # set-up, reported in the line.
-    plan = eng.plan(wps, VELOCITY, DT)                   # allocates; also the first warm-up
+    plan = eng.plan(wps, VELOCITY, DT, placement_trials=1)          # allocates (first allocation, no search); also the first warm-up
     fleet = eng.fleet(plan)
     log = torch.empty((CHUNK, 13, B), dtype=torch.float64, device=dev)
     n_chunks = TICKS // CHUNK
@@ -453,7 +453,7 @@ def main():
             torch.cuda.synchronize()
         per_launch = [a.elapsed_time(b) for a, b in pairs]
         # the same missions flown at half the speed (velocity 1.5: legs demand < 2.5 m/s^2): nobody departs
-        slow = eng.plan(wps, VELOCITY / 2, DT)
+        slow = eng.plan(wps, VELOCITY / 2, DT, placement_trials=1)
         fl2 = eng.fleet(slow)
         a, b = ev(), ev()
         for _ in range(2):
@@ -485,7 +485,7 @@ def main():
         lo4, hi4 = shard_bounds(C4_TOTAL, rank, world)          # contiguous blocks; any N (sizes differ by at most one)
         B4 = hi4 - lo4
         wps4 = missions(C4_TOTAL, C4_SEGMENTS, lo4, hi4)
-        plan4 = eng.plan(wps4, VELOCITY, DT)
+        plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)
         fleet4 = eng.fleet(plan4)
         log4 = torch.empty((CHUNK, 13, B4), dtype=torch.float64, device=dev)
 

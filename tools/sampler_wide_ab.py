@@ -11,7 +11,7 @@ NB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 eng = Engine("cuda:0")
-plan = eng.plan(missions(B, m, 0, B), 3.0, 0.01)
+plan = eng.plan(missions(B, m, 0, B), 3.0, 0.01, placement_trials=1)
 bufs = [plan.traj] + [torch.empty_like(plan.traj) for _ in range(NB - 1)]
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 res = {w: [[] for _ in bufs] for w in (1, 4, 8, 16)}

@@ -152,6 +152,7 @@ class RRTDeviceBatch:
 class Engine:
     """One GPU, one `uavac_ctx`.  Kernels are enqueued on torch's current stream for that device."""
     FAST_ROW_BUFFER_BYTES_PER_S = 5.6e12       # `place_rows`: a row buffer the sampler fills at this rate is of the fast kind
+    DEFAULT_PLACEMENT_TRIALS = 4               # `plan`: candidates tried for large row buffers when the caller does not say
 
     def __init__(self, device=None):
         torch = _torch()
@@ -181,7 +182,7 @@ class Engine:
 
     # -- planning ---------------------------------------------------------------
     def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True, dense_yaw: bool = False,
-             placement_trials: int = 1) -> Plan:
+             placement_trials: int = None) -> Plan:
         """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124).
         `strict`: raise UavacError(ESINGULAR) when a mission's knot system is singular (a repeated waypoint) instead of
         returning NaN coefficients for it; with strict=False inspect `plan.status`.
@@ -191,7 +192,8 @@ class Engine:
         ~5.1 TB/s -- a property of the allocation that lasts as long as the buffer (tools/buffer_placement_probe.py, DESIGN
         K2).  So allocate up to that many candidate buffers one after the other, time the sampler on each, stop at the first
         one the rows stream into at >= 5.6 TB/s (the fast kind), keep the fastest and free the others (`plan.placement_ms`
-        holds the times).  Optional, for plans that are re-sampled many times (`replan`); the default takes the first allocation."""
+        holds the times).  1 = take the first allocation.  Default (None): 4 for row buffers of 1 GiB and more when the GPU
+        has room for the candidates side by side (where the effect is worth ~15 % of every later `replan`), else 1."""
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -215,6 +217,10 @@ class Engine:
         first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
         plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw, first_yaw)
         self.sample(plan)
+        if placement_trials is None:
+            row_bytes = total * nat.TRAJ_COLS * 8
+            free = torch.cuda.mem_get_info(self.device)[0] if row_bytes >= (1 << 30) else 0
+            placement_trials = self.DEFAULT_PLACEMENT_TRIALS if (row_bytes >= (1 << 30) and free > 4 * row_bytes) else 1
         if int(placement_trials) > 1 and total > 0:
             self.place_rows(plan, int(placement_trials))
         if strict:
