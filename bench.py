@@ -487,7 +487,7 @@ def main():
         wps4 = missions(C4_TOTAL, C4_SEGMENTS, lo4, hi4)
         plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)
         fleet4 = eng.fleet(plan4)
-        log4 = torch.empty((CHUNK, 13, B4), dtype=torch.float64, device=dev)
+        log4 = torch.empty((CHUNK, 13, -(-B4 // 16) * 16), dtype=torch.float64, device=dev)     # rows on 128-byte lines for any B4
 
         def fly4():
             fleet4.reset()
@@ -623,7 +623,8 @@ def main():
                 # planning ends, so their transfer (rows), or the transfer of the plan and the root's re-sampling, starts
                 # there on a second stream while the vehicles fly.  A problem here is reported (`overlap_error`) but does
                 # not fail the run -- the verified serial gathers above are the ones that count.
-                if gather_err is None and not rehearsal:
+                # (whether to go on is decided by all ranks together: only rank 0 knows what its verifications found)
+                if everybody_fine(gather_err) and not rehearsal:
                     side = torch.cuda.Stream(device=dev)
 
                     def overlapped(begin):
