@@ -156,16 +156,14 @@ def self_launch(args, argv):
         # rank 0's stdout carries the JSON line; whatever the other ranks print goes to this process's stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    deadline = None
+    out0, _ = procs[0].communicate()                            # rank 0 prints the line last and leaves
     codes = [procs[0].returncode] + [None] * (n - 1)
+    deadline = time.time() + 120.0                              # the other ranks get two minutes to follow it out
     while any(c is None for c in codes):
         for r in range(1, n):
             if codes[r] is None:
                 codes[r] = procs[r].poll()
-        if any(c not in (None, 0) for c in codes) or all(c is not None for c in codes[:1]):
-            deadline = deadline or time.time() + 120.0          # rank 0 is done (or somebody failed): the rest gets two minutes
-        if deadline and time.time() > deadline:
+        if time.time() > deadline:
             for r in range(1, n):
                 if codes[r] is None:
                     procs[r].kill()                             # exactly the children started above
