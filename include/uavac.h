@@ -249,6 +249,18 @@ int uavac_minsnap_obstacle_round_dev(uavac_ctx *ctx, const double *wp, const int
                                      int32_t *touched, double *wp_out, int64_t *seg_offsets_out, int32_t *counters,
                                      double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs, int32_t *hit);
 
+/* The whole obstacle loop on HOST buffers: MinimumSnap(path_b, obstacles, velocity, dt) up to the final waypoint list, for B
+ * ragged missions (wp [S + B][3], seg_offsets [B+1] as above) against n_cuboids cuboids [n_cuboids][6] visited in order
+ * (minimum_snap.py:72-93: earlier ones are not re-checked).  Unlike the reference's, the loop is bounded: at most
+ * max_iterations + 1 rounds per obstacle; a mission that runs out, or would outgrow UAVAC_MAX_SEGMENTS, keeps the waypoints
+ * it has and is reported in converged [B] (0; may be NULL).  recheck_passes > 0 sweeps the missions that received midpoints
+ * over the obstacle list again (beyond the reference).  Output: the final waypoints wp_out [seg_offsets_out[B] + B][3]
+ * (wp_capacity rows available; B * (UAVAC_MAX_SEGMENTS + 1) always suffice; UAVAC_EINVAL with seg_offsets_out filled in when
+ * it is too small) -- sample them with uavac_minsnap_plan_ragged to get get_trajectory()'s rows. */
+int uavac_minsnap_obstacle_waypoints(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, double velocity,
+                                     double dt, const double *cuboids, int n_cuboids, int max_iterations, int recheck_passes,
+                                     double *wp_out, int64_t wp_capacity, int64_t *seg_offsets_out, int32_t *converged);
+
 /* MinimumSnap._calculate_yaws (minimum_snap.py:126-136) on its own, for B independent velocity
  * sequences of any length: sequence b = rows [offsets[b], offsets[b+1]) of velocities[.][3] (only
  * vx, vy are read); yaws[offsets[B]].  Headings of rows with |v_xy| >= 1e-3, np.unwrap over those,

@@ -62,6 +62,7 @@ int main(void) {
     EXPECT(uavac_minsnap_sample_ragged_dev(NULL, d, i32, i64, i64, 1, 1, 1, 0.01, d, 1, d, i32, d) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_obstacle_round_dev(NULL, d, i64, 1, 1, 1.0, 0.01, d, i32, i32, i32, d, i64, i32, d, i32, i64, d, i32) ==
            UAVAC_EINVAL);
+    EXPECT(uavac_minsnap_obstacle_waypoints(NULL, d, i64, 1, 1.0, 0.01, d, 1, 4, 0, d, 8, i64, i32) == UAVAC_EINVAL);
     EXPECT(uavac_yaw_scan_dev(NULL, d, i64, 1, d) == UAVAC_EINVAL && uavac_yaw_scan(NULL, d, 1, d) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_row_counts(NULL, d, 1, 1, 1.0, 0.01, d, i32, i64) == UAVAC_EINVAL);
     EXPECT(uavac_minsnap_solve(NULL, d, 1, 1, 1.0, d, d) == UAVAC_EINVAL);
@@ -100,6 +101,6 @@ int main(void) {
     EXPECT(uavac_gather_rows_dev(NULL, NULL, d, 1, 11, i64, 0, d) == UAVAC_EINVAL);
     EXPECT(uavac_gather_plan_dev(NULL, NULL, d, d, i32, 1, i64, 0, d, d, i32) == UAVAC_EINVAL);
     EXPECT(uavac_comm_finish(NULL, NULL) == UAVAC_EINVAL && uavac_comm_loopback_dev(NULL, NULL, d, d, 1) == UAVAC_EINVAL);
-    printf("asan driver: %d entry points answered a GPU-less host as documented\n", 71);
+    printf("asan driver: %d entry points answered a GPU-less host as documented\n", 72);
     return 0;
 }

@@ -367,3 +367,41 @@ def test_ragged_plan_gather_world1_and_plan_fed_flight_of_an_obstacle_corrected_
     f = eng.fleet(gp, from_plan=True)
     log, _ = f.rollout(900, state_log=True)
     assert torch.equal(log, flights[0][0])
+
+
+def test_host_pointer_obstacle_loop_equals_the_engine(eng, nat):
+    """uavac_minsnap_obstacle_waypoints (plain host buffers, the whole obstacle loop inside one C call) against
+    Engine.plan_collision_free: same final waypoint lists and give-up flags, with and without re-check sweeps; then the rows
+    through uavac_minsnap_plan_ragged equal the engine's."""
+    lab = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0],
+                    [13.3, 14.7, 6.3, 7.7, -6.0, 0.0], [20.2, 20.8, 4.0, 10.0, -3.3, -2.7]])
+    wps = _missions(400, 8)
+    ragged = [np.ascontiguousarray(w[:n]) for w, n in zip(wps, np.random.default_rng(3).integers(2, 10, len(wps)))]
+    B = len(ragged)
+    so = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum([len(w) - 1 for w in ragged], out=so[1:])
+    flat = np.ascontiguousarray(np.concatenate(ragged))
+    for passes in (0, 2):
+        ref = eng.plan_collision_free(ragged, lab, 3.0, 0.01, strict=False, max_iterations=10, recheck_passes=passes)
+        cap = B * (nat.MAX_SEGMENTS + 1)
+        wp_out, so_out, ok = np.empty((cap, 3)), np.empty(B + 1, dtype=np.int64), np.zeros(B, dtype=np.int32)
+        eng.ctx.call("uavac_minsnap_obstacle_waypoints", nat.np_ptr(flat), nat.np_ptr(so), B, 3.0, 0.01, nat.np_ptr(lab), len(lab), 10,
+                     passes, nat.np_ptr(wp_out), cap, nat.np_ptr(so_out), nat.np_ptr(ok))
+        assert np.array_equal(ok.astype(bool), ref.converged) and (~ref.converged).sum() >= 1
+        for b in range(B):
+            got = wp_out[so_out[b] + b:so_out[b + 1] + b + 1]
+            assert np.array_equal(got, ref.final_waypoints[b]), b
+        # rows of the final waypoints through the host-pointer ragged planner
+        S = int(so_out[-1])
+        ro = np.empty(B + 1, dtype=np.int64)
+        final = np.ascontiguousarray(wp_out[:S + B])
+        eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(final), nat.np_ptr(so_out), B, 3.0, 0.01, None, nat.np_ptr(ro), None, None, 0)
+        rows = np.empty((int(ro[-1]), 11))
+        eng.ctx.call("uavac_minsnap_plan_ragged", nat.np_ptr(final), nat.np_ptr(so_out), B, 3.0, 0.01, None, nat.np_ptr(ro), None,
+                     nat.np_ptr(rows), len(rows))
+        assert np.array_equal(ro, ref.row_offsets.cpu().numpy()) and np.array_equal(rows, ref.traj.cpu().numpy())
+    # capacity too small: refused with the needed size reported
+    with pytest.raises(nat.UavacError):
+        eng.ctx.call("uavac_minsnap_obstacle_waypoints", nat.np_ptr(flat), nat.np_ptr(so), B, 3.0, 0.01, nat.np_ptr(lab), len(lab), 10, 0,
+                     nat.np_ptr(wp_out), 5, nat.np_ptr(so_out), nat.np_ptr(ok))
+    assert so_out[-1] >= so[-1]

@@ -700,6 +700,99 @@ int uavac_minsnap_plan_ragged(uavac_ctx *ctx, const double *wp, const int64_t *s
     return UAVAC_OK;
 }
 
+// The obstacle loop of MinimumSnap._generate_collision_free_trajectory (minimum_snap.py:63-95) for B ragged missions on HOST
+// buffers: every round is uavac_minsnap_obstacle_round_dev on device scratch of this ctx, the host keeps the bookkeeping the
+// reference keeps (obstacles in order, earlier ones not re-checked; a bounded number of rounds per obstacle; optional re-check
+// sweeps over the missions that received midpoints).  Returns the final waypoint lists; sample them with
+// uavac_minsnap_plan_ragged.
+int uavac_minsnap_obstacle_waypoints(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, double velocity,
+                                     double dt, const double *cuboids, int n_cuboids, int max_iterations, int recheck_passes,
+                                     double *wp_out, int64_t wp_capacity, int64_t *seg_offsets_out, int32_t *converged) {
+    UAVAC_ENTER(ctx);
+    if (B < 1 || !wp || !seg_offsets || !wp_out || !seg_offsets_out || n_cuboids < 0 || (n_cuboids > 0 && !cuboids))
+        return uavac_fail(ctx, UAVAC_EINVAL, "bad B or null pointer");
+    if (seg_offsets[0] != 0) return uavac_fail(ctx, UAVAC_EINVAL, "seg_offsets must start at 0");
+    if (max_iterations < 0 || recheck_passes < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative iteration count");
+    int max_m = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t mb = seg_offsets[b + 1] - seg_offsets[b];
+        if (mb < 1 || mb > UAVAC_MAX_SEGMENTS)
+            return uavac_fail(ctx, UAVAC_EINVAL, "every mission needs 1 .. UAVAC_MAX_SEGMENTS segments");
+        if (mb > max_m) max_m = (int)mb;
+    }
+    const size_t S0 = (size_t)seg_offsets[B], nB = (size_t)B;
+    if (!finite_all(wp, (S0 + nB) * 3) || (n_cuboids && !finite_all(cuboids, (size_t)n_cuboids * 6)) || !std::isfinite(velocity) ||
+        !std::isfinite(dt))
+        return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite waypoint, cuboid, velocity or dt");
+    if (!(velocity > 0.0) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity and dt must be > 0");
+    const size_t S_cap = nB * UAVAC_MAX_SEGMENTS, W_cap = (S_cap + nB) * 3;         // no mission ever has more segments
+    if (int rc = uavac_arena_reserve(ctx, 2 * uavac_arena_size(W_cap * 8) + 2 * uavac_arena_size((nB + 1) * 8) +
+                                              4 * uavac_arena_size(nB * 4) + uavac_arena_size(16) + uavac_arena_size(S_cap * 8) +
+                                              2 * uavac_arena_size(S_cap * 4) + uavac_arena_size((nB + 1) * 8) +
+                                              uavac_arena_size(S_cap * 192) + uavac_arena_size((size_t)(n_cuboids ? n_cuboids : 1) * 48)))
+        return rc;
+    double *wp_a = take<double>(ctx, W_cap), *wp_b = take<double>(ctx, W_cap);
+    int64_t *so_a = take<int64_t>(ctx, nB + 1), *so_b = take<int64_t>(ctx, nB + 1);
+    int32_t *d_active = take<int32_t>(ctx, nB), *d_overflow = take<int32_t>(ctx, nB), *d_touched = take<int32_t>(ctx, nB);
+    int32_t *d_spare = take<int32_t>(ctx, nB);
+    (void)d_spare;
+    int32_t *d_counters = take<int32_t>(ctx, 4);
+    double *d_times = take<double>(ctx, S_cap);
+    int32_t *d_seg_rows = take<int32_t>(ctx, S_cap), *d_hit = take<int32_t>(ctx, S_cap);
+    int64_t *d_row_offsets = take<int64_t>(ctx, nB + 1);
+    double *d_coeffs = take<double>(ctx, S_cap * 24);
+    double *d_cub = take<double>(ctx, (size_t)(n_cuboids ? n_cuboids : 1) * 6);
+    if (int rc = clear_flags(ctx)) return rc;
+    if (int rc = h2d_staged(ctx, wp_a, wp, (S0 + nB) * 24)) return rc;
+    if (int rc = h2d_staged(ctx, so_a, seg_offsets, (nB + 1) * 8)) return rc;
+    if (n_cuboids) if (int rc = h2d_staged(ctx, d_cub, cuboids, (size_t)n_cuboids * 48)) return rc;
+    UAVAC_HIP(ctx, hipMemsetAsync(d_overflow, 0, nB * 4, ctx->stream));
+    std::vector<int32_t> todo(nB, 1), failed(nB, 0), active(nB), touched(nB), overflow(nB);
+    for (int sweep = 0; sweep <= recheck_passes && n_cuboids > 0; ++sweep) {
+        UAVAC_HIP(ctx, hipMemsetAsync(d_touched, 0, nB * 4, ctx->stream));
+        for (int c = 0; c < n_cuboids; ++c) {
+            int n_active = 0;
+            for (size_t b = 0; b < nB; ++b) { active[b] = todo[b] && !failed[b]; n_active += active[b]; }
+            if (int rc = h2d_staged(ctx, d_active, active.data(), nB * 4)) return rc;
+            int it = 0;
+            for (; it <= max_iterations && n_active > 0; ++it) {
+                if (int rc = uavac_minsnap_obstacle_round_dev(ctx, wp_a, so_a, B, max_m, velocity, dt, d_cub + 6 * c, d_active,
+                                                              d_overflow, d_touched, wp_b, so_b, d_counters, d_times, d_seg_rows,
+                                                              d_row_offsets, d_coeffs, d_hit)) return rc;
+                std::swap(wp_a, wp_b);
+                std::swap(so_a, so_b);
+                int32_t cnt[4];
+                if (int rc = d2h_staged(ctx, cnt, d_counters, 16)) return rc;           // the round's one read-back (synchronises)
+                n_active = cnt[0];
+                if (cnt[2] > max_m) max_m = cnt[2];
+                if (cnt[1]) {                                                           // outgrew UAVAC_MAX_SEGMENTS: stays as it is
+                    if (int rc = d2h_staged(ctx, overflow.data(), d_overflow, nB * 4)) return rc;
+                    for (size_t b = 0; b < nB; ++b) failed[b] |= overflow[b];
+                }
+            }
+            if (n_active > 0) {                                                         // the bounded loop ran out
+                if (int rc = d2h_staged(ctx, active.data(), d_active, nB * 4)) return rc;
+                for (size_t b = 0; b < nB; ++b) failed[b] |= (active[b] != 0);
+            }
+        }
+        if (int rc = d2h_staged(ctx, touched.data(), d_touched, nB * 4)) return rc;
+        int again = 0;
+        for (size_t b = 0; b < nB; ++b) { todo[b] = touched[b] && !failed[b]; again += todo[b]; }
+        if (!again) break;                                                              // only missions that changed can have new conflicts
+    }
+    if (int rc = d2h_staged(ctx, seg_offsets_out, so_a, (nB + 1) * 8)) return rc;
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t n_wp = seg_offsets_out[B] + B;
+    int32_t fl[4];
+    if (int rc = read_flags(ctx, fl)) return rc;
+    if (fl[0]) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite segment duration");
+    if (n_wp > wp_capacity) return uavac_fail(ctx, UAVAC_EINVAL, "wp_capacity too small: seg_offsets_out[B] + B waypoints are needed");
+    if (int rc = d2h_staged(ctx, wp_out, wp_a, (size_t)n_wp * 24)) return rc;
+    UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (converged) for (size_t b = 0; b < nB; ++b) converged[b] = failed[b] ? 0 : 1;
+    return UAVAC_OK;
+}
+
 int uavac_yaw_scan(uavac_ctx *ctx, const double *velocities, int64_t n, double *yaws) {
     UAVAC_ENTER(ctx);
     if (n < 0 || (n > 0 && (!velocities || !yaws))) return uavac_fail(ctx, UAVAC_EINVAL, "bad n or null pointer");

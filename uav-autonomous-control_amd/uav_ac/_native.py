@@ -84,6 +84,8 @@ _SIGNATURES = {
     "uavac_minsnap_sample_ragged_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_double, _P,
                                                    C.c_int64, _P, _P, _P]),
     "uavac_minsnap_obstacle_round_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_double] + [_P] * 12),
+    "uavac_minsnap_obstacle_waypoints": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, _P, C.c_int, C.c_int, C.c_int, _P,
+                                                    C.c_int64, _P, _P]),
     "uavac_yaw_scan_dev": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "uavac_yaw_scan": (C.c_int, [_P, _P, C.c_int64, _P]),
     "uavac_minsnap_row_counts": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P]),

@@ -17,7 +17,6 @@ from .. import _native as nat
 from .._single import ctx
 
 
-_ENGINE = None          # lazily created device engine for the obstacle loop
 
 
 class MinimumSnap:
@@ -90,14 +89,22 @@ class MinimumSnap:
             self.reset()
             self._generate_trajectory()
             return
-        from ..fleet import Engine
-        global _ENGINE
-        if _ENGINE is None:
-            _ENGINE = Engine()
-        rp = _ENGINE.plan_collision_free([nat.as_f64(self.waypoints)], self.coord_obstacles, self.velocity, self.dt,
-                                         max_iterations=self.MAX_REPLAN_ITERATIONS)
+        # the whole loop in one call of the C ABI (host buffers; every round runs on the GPU): uavac_minsnap_obstacle_waypoints
+        wp = nat.as_f64(self.waypoints)
+        m = len(wp) - 1
+        cub = nat.as_f64(self.coord_obstacles).reshape(-1, 6)
+        so = np.array([0, m], dtype=np.int64)
+        cap = nat.MAX_SEGMENTS + 1
+        wp_out, so_out = np.empty((cap, 3)), np.empty(2, dtype=np.int64)
+        ok = np.zeros(1, dtype=np.int32)
+        ctx().call("uavac_minsnap_obstacle_waypoints", nat.np_ptr(wp), nat.np_ptr(so), 1, float(self.velocity), float(self.dt),
+                   nat.np_ptr(cub), len(cub), int(self.MAX_REPLAN_ITERATIONS), 0, nat.np_ptr(wp_out), cap, nat.np_ptr(so_out),
+                   nat.np_ptr(ok))
+        if not ok[0]:            # the reference would loop for ever (a waypoint inside a cuboid, a leg crossing one squarely)
+            raise RuntimeError("obstacle correction did not converge (a waypoint inside an obstacle?)")
+        final = wp_out[:int(so_out[1]) + 1].copy()
         self.reset()
-        self.waypoints = rp.final_waypoints[0]
+        self.waypoints = final
         self._generate_trajectory()              # fills times / coeffs / A / b for the final waypoint list
 
     # ------------------------------------------------------- inspection helpers (host, not on the GPU path)
