@@ -4,7 +4,7 @@
  * libuavac.so (host-pointer entry points; the library stages through device memory itself).  Then the same flight
  * tick by tick through the resident session (uavac_pilot_*: what a host-owned `tc.step(); sim.step()` loop uses), from the
  * ground with the build-defined ground plane, the stand-alone yaw scan, a ragged batch (missions of different lengths in
- * one call), and the multi-GPU gather's RCCL calls on this one
+ * one call), an obstacle-aware course (the midpoint loop in one call), and the multi-GPU gather's RCCL calls on this one
  * GPU (communicator of world size 1: counts, the root's own block, a self send/receive through the transport).
  *
  *   gcc examples/c_abi_demo.c -Iinclude -Luav-autonomous-control_amd/lib -luavac \
@@ -104,6 +104,30 @@ int main(void) {
            (long long)(roffs[2] - roffs[1]), ragged_same ? "yes" : "no");
     free(rtraj);
     if (!ragged_same) return 3;
+
+    /* ---- MinimumSnap(path, obstacles, 2.0, 0.01).get_trajectory() from plain C: the obstacle case of the reference's own
+     * test (tests/unit/planning/test_minimum_snap.py:171-183) -- the second leg clips a cuboid and receives one midpoint ---- */
+    const double corner[3][3] = {{0, 0, 1}, {3, 0, 1}, {3, 3, 1}};
+    const double cuboid[1][6] = {{3.2, 4.0, 0.5, 1.5, 0.0, 2.0}};
+    const int64_t corner_offsets[2] = {0, 2};
+    double final_wp[UAVAC_MAX_SEGMENTS + 1][3];
+    int64_t final_offsets[2], corner_rows[2];
+    int32_t converged = 0;
+    CHECK(uavac_minsnap_obstacle_waypoints(ctx, &corner[0][0], corner_offsets, 1, velocity, dt, &cuboid[0][0], 1, /*max_iterations=*/64,
+                                           /*recheck_passes=*/0, &final_wp[0][0], UAVAC_MAX_SEGMENTS + 1, final_offsets, &converged));
+    CHECK(uavac_minsnap_plan_ragged(ctx, &final_wp[0][0], final_offsets, 1, velocity, dt, NULL, corner_rows, NULL, NULL, 0));
+    double *corner_traj = malloc(sizeof(double) * UAVAC_TRAJ_COLS * (size_t)corner_rows[1]);
+    CHECK(uavac_minsnap_plan_ragged(ctx, &final_wp[0][0], final_offsets, 1, velocity, dt, NULL, corner_rows, NULL, corner_traj,
+                                    corner_rows[1]));
+    int inside = 0;
+    for (int64_t r = 0; r < corner_rows[1]; ++r) {
+        const double *p = corner_traj + UAVAC_TRAJ_COLS * (size_t)r, *c = cuboid[0];
+        inside += p[0] >= c[0] && p[0] <= c[1] && p[1] >= c[2] && p[1] <= c[3] && p[2] >= c[4] && p[2] <= c[5];
+    }
+    printf("obstacle-aware plan: %lld -> %lld splines, %lld rows, converged %d, rows inside the cuboid %d\n",
+           (long long)corner_offsets[1], (long long)final_offsets[1], (long long)corner_rows[1], (int)converged, inside);
+    free(corner_traj);
+    if (!converged || inside || final_offsets[1] != 3 || corner_rows[1] != 413) return 3;     /* the reference: 4 waypoints, 413 rows */
 
     /* ---- the gather of the multi-GPU path with a communicator of one rank (N GPUs: one process each, same calls) ---- */
     char id[UAVAC_COMM_ID_BYTES];
