@@ -80,3 +80,16 @@ def test_two_real_gpus_over_rccl_when_the_box_has_them():
     c4 = line["config4"]
     assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True and "overlap_error" not in c4
     assert c4["plan_overlapped_verified"] is True and c4["overlapped_verified"] is True
+
+
+def test_ranks_started_by_torch_distributed_run_are_not_launched_again():
+    """The driver's own form: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.  WORLD_SIZE is set,
+    so bench.py is a rank, not a launcher: exactly one line, from rank 0."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29581", BENCH, "--gpus", "2", "--launch-check"], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
