@@ -234,16 +234,12 @@ def test_placeholder_wave_between_compute_and_store_wave_changes_no_bit(eng):
     assert torch.equal(logs[0], logs[1])
 
 
-@pytest.mark.parametrize("waves", [4, 8, 16])
-def test_wide_sampler_equals_the_one_wave_sampler_bit_for_bit(eng, waves):
-    """minsnap_sample_wide.hip (W wavefronts per mission, the yaw scan combined across waves through LDS) against
-    minsnap_sample.hip (one wavefront walks the mission): rows and first headings, bit for bit -- on the 8(d) missions, on
-    missions that climb vertically for more than a round of 1 024 rows before their first heading (placeholders patched
-    across waves), on missions that circle (headings wrap: the slow, ordered path of the scan) and on one-row legs."""
-    import torch
-    rng = np.random.default_rng(77 + waves)
+def _sampler_cases(seed):
+    """Missions that exercise every path of the sampler's yaw scan and row layout: the 8(d) missions, one-spline missions,
+    a fine time step, long vertical climbs (no heading for 1 800-2 700 rows: placeholders patched later), circles (headings
+    wrap in many chunks: the ordered path of the scan) and legs of 1-3 rows."""
+    rng = np.random.default_rng(seed)
     cases = [(_missions(300, 12), 3.0, 0.01), (_missions(64, 1), 3.0, 0.01), (_missions(50, 20), 0.9, 0.004)]
-    # long vertical climb (no heading for 1 800-2 700 rows), then a horizontal course
     climb = []
     for i in range(40):
         h = rng.uniform(8.0, 12.0)
@@ -251,7 +247,6 @@ def test_wide_sampler_equals_the_one_wave_sampler_bit_for_bit(eng, waves):
         legs = np.cumsum(rng.uniform(-3, 3, (5, 3)) * np.array([1, 1, 0.1]), axis=0)
         climb.append(np.vstack([p0, p0 + [0, 0, -h], p0 + [0, 0, -h] + legs]))
     cases.append((np.stack(climb), 1.0, 0.01))
-    # circles: three and a half turns, both senses -> np.unwrap corrections in many 64-row chunks
     circ = []
     for i in range(40):
         n, sense = 29, (1 if i % 2 else -1)
@@ -259,24 +254,70 @@ def test_wide_sampler_equals_the_one_wave_sampler_bit_for_bit(eng, waves):
         rad = rng.uniform(1.5, 4.0)
         circ.append(np.stack([10 + rad * np.cos(th), 10 + rad * np.sin(th), -3 + 0.1 * np.sin(3 * th)], axis=1))
     cases.append((np.stack(circ), 2.0, 0.01))
-    # very short legs (1-3 rows per spline) and a coarse step
     cases.append((_missions(100, 6) * 0.02, 3.0, 0.01))
-    for wps, v, dt in cases:
+    return cases
+
+
+@pytest.mark.parametrize("waves,group", [(8, 1), (4, 1), (16, 1), (8, 2), (8, 5), (4, 3), (16, 7)])
+def test_streaming_sampler_equals_the_one_wave_sampler_bit_for_bit(eng, waves, group):
+    """minsnap_sample_stream.hip (workgroups of W wavefronts stream the 64-row chunks of G consecutive missions in address
+    order, the yaw scan's carry handed from wave to wave through LDS) against minsnap_sample.hip (one wavefront walks a
+    mission): rows and first headings bit for bit, for every W and G, and whatever the row buffer's alignment (the chunk
+    grid follows the buffer's address: three offsets of the same rows)."""
+    import torch
+    for wps, v, dt in _sampler_cases(77 + waves):
         got = {}
         for sw in (1, waves):
             eng.ctx.set_option("sampler_waves", sw)
+            eng.ctx.set_option("sampler_group", group)
             try:
-                plan = eng.plan(wps, v, dt)
+                plan = eng.plan(wps, v, dt, placement_trials=1)
                 plan.traj.fill_(float("nan"))
                 plan.first_yaw.fill_(float("nan"))
                 eng.replan(plan)                               # the one-call chain takes the same sampler
                 assert eng.take_flags() == [0, 0, 0, 0]
                 got[sw] = (plan.traj.clone(), plan.first_yaw.clone(), plan.row_offsets.clone())
+                if sw != 1:
+                    for off in (1, 6, 11):                     # the same rows into a buffer that starts `off` doubles later
+                        big = torch.full((plan.total_rows * 11 + 32,), float("nan"), dtype=torch.float64, device=eng.device)
+                        keep = plan.traj
+                        plan.traj = big[off:off + plan.total_rows * 11].view(plan.total_rows, 11)
+                        eng.sample(plan)
+                        assert torch.equal(plan.traj, got[sw][0]), off
+                        assert bool(torch.isnan(big[:off]).all()) and bool(torch.isnan(big[off + plan.total_rows * 11:]).all())
+                        plan.traj = keep
             finally:
-                eng.ctx.set_option("sampler_waves", 1)
+                eng.ctx.set_option("sampler_waves", 8)
+                eng.ctx.set_option("sampler_group", 1)
         assert torch.equal(got[1][2], got[waves][2])
         assert not bool(torch.isnan(got[waves][0]).any())
         assert torch.equal(got[1][0], got[waves][0]) and torch.equal(got[1][1], got[waves][1])
+
+
+def test_streaming_sampler_variants_equal_the_one_wave_sampler(eng):
+    """The streaming sampler's other outputs -- dense yaw column, jerk / snap, hit flags of a cuboid, ragged batches --
+    against the one-wave-per-mission kernel, bit for bit."""
+    import torch
+    lab = np.array([[3.7, 4.3, 4.0, 10.0, -3.4, -2.8], [10.7, 11.3, 4.0, 10.0, -2.2, 0.0]])
+    for wps, v, dt in _sampler_cases(5)[:5]:
+        out = {}
+        for sw, g in ((1, 1), (8, 1), (4, 3)):
+            eng.ctx.set_option("sampler_waves", sw)
+            eng.ctx.set_option("sampler_group", g)
+            try:
+                plan = eng.plan(wps, v, dt, dense_yaw=True, placement_trials=1)
+                jerk, snap = eng.sample_derivatives(plan)
+                rag = eng.plan_ragged([w[: 2 + (i % (len(w) - 1))] for i, w in enumerate(wps)], v, dt, cuboid=lab[0])
+                out[(sw, g)] = (plan.traj.clone(), plan.yaw.clone(), jerk.clone(), snap.clone(), rag.traj.clone(), rag.hit.clone(),
+                                rag.first_yaw.clone())
+            finally:
+                eng.ctx.set_option("sampler_waves", 8)
+                eng.ctx.set_option("sampler_group", 1)
+        ref = out[(1, 1)]
+        assert torch.equal(ref[1], ref[0][:, 9])
+        for key, val in out.items():
+            for x, y in zip(ref, val):
+                assert torch.equal(x, y), key
 
 
 def test_obstacle_loop_on_the_device_equals_the_host_side_loop(eng):

@@ -21,6 +21,22 @@ __device__ __forceinline__ void minsnap_eval_row(const double *c, double t, doub
     ax = 2.0 * d2x; ay = 2.0 * d2y; az = 2.0 * d2z;
 }
 
+// One axis of the same sample (axis a = 0, 1, 2): the identical fma sequence as minsnap_eval_row, hence the same bits; the
+// sampler evaluates axis after axis and stages each at once, which keeps a third of the coefficients and sums in registers.
+template <int STRIDE>
+__device__ __forceinline__ void minsnap_eval_axis(const double *c, int a, double t, double &p, double &v, double &acc) {
+    double d1 = 0, d2 = 0;
+    p = c[(21 + a) * STRIDE];
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+        d2 = fma(d2, t, d1);
+        d1 = fma(d1, t, p);
+        p = fma(p, t, c[(3 * i + a) * STRIDE]);
+    }
+    v = d1;
+    acc = 2.0 * d2;
+}
+
 // Third and fourth derivative of the same polynomials (polynom(8, 3, t) @ coeffs and polynom(8, 4, t) @ coeffs,
 // minimum_snap.py:111-112): Horner with running derivatives carried two levels further, d_k = p^(k) / k!.
 template <int STRIDE>

@@ -296,14 +296,13 @@ int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg
                  (x.yaw_dense ? sizeof(double) * yg * SB : 0);
     const bool hits = x.aabb && x.hit, derivs = x.jerk || x.snap;
     const bool ragged = x.seg_offsets != nullptr;
-    // rows (+ first headings) only, one segment count for the batch: the W-waves-per-mission kernel (minsnap_sample_wide.hip)
-    if (plain && !ragged && !x.yaw_dense && ctx->sampler_waves > 1)
-        return uavac_launch_sample_wide(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x.capacity_rows, x.first_yaw,
-                                        ctx->sampler_waves);
     if (ragged && (derivs || x.yaw_dense || x.total_segments < 0))
         return uavac_fail(ctx, UAVAC_EINVAL, "ragged sampling: rows (+ hit flags, first yaws) only, and the segment total");
     if (hits)
         UAVAC_HIP(ctx, hipMemsetAsync(x.hit, 0, sizeof(int32_t) * (ragged ? (size_t)x.total_segments : (size_t)B * m), ctx->stream));
+    // default: the chunk-streaming kernel (minsnap_sample_stream.hip); sampler_waves == 1 keeps the one-wave-per-mission form
+    if (ctx->sampler_waves > 1)
+        return uavac_launch_sample_stream(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x, ctx->sampler_waves, ctx->sampler_group);
 #define UAVAC_SAMPLE(H, D, Y)                                                                                          \
     hipLaunchKernelGGL((minsnap_sample_kernel<H, D, Y>), dim3(B), dim3(SB), lds, ctx->stream, coeffs, seg_rows, row_offsets, \
                        B, m, dt, traj, x.aabb, x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags, x.first_yaw, \

@@ -30,7 +30,8 @@ struct uavac_ctx {
     size_t pin_cap = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::string err;
-    int sampler_waves = 1;           // wavefronts per mission of the plain sampler: 1 (minsnap_sample.hip), 4, 8, 16 (minsnap_sample_wide.hip)
+    int sampler_waves = 4;           // tuning: wavefronts per workgroup of the sampler: 4, 8, 16 (minsnap_sample_stream.hip); 1 = one wave per mission (minsnap_sample.hip)
+    int sampler_group = 1;           // tuning: consecutive missions per workgroup of the streaming sampler
     int yaw_group = 8;               // tuning: chunks of the sampler's dense yaw column that leave together (1, 4, 8, 16)
     int rollout_align = 1;           // tuning: launch the 2-wave aligner kernel before a logged launch of shape 1
     int late_handover = -1;          // tuning: -1 = the launcher picks per launch; 0 / 1 = slab handed over at the end of the tick / a third of a tick later
@@ -176,9 +177,10 @@ struct SampleExtras {
 };
 int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets,
                         int B, int m, double dt, double *traj, const SampleExtras &x);
-// the same rows from a workgroup of `waves` (4, 8, 16) wavefronts per mission (minsnap_sample_wide.hip): rows + first headings only
-int uavac_launch_sample_wide(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets, int B,
-                             int m, double dt, double *traj, int64_t capacity_rows, double *first_yaw, int waves);
+// the same rows from workgroups of `waves` (4, 8, 16) wavefronts that stream the 64-row chunks of `group` consecutive missions
+// in address order (minsnap_sample_stream.hip)
+int uavac_launch_sample_stream(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets, int B,
+                               int m, double dt, double *traj, const SampleExtras &x, int waves, int group);
 int uavac_launch_yaw_scan(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B, double *yaws);
 int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positions, int B, int hover, double *state,
                             int32_t *istate);
