@@ -57,7 +57,6 @@ B_PER_GPU = 65536
 SEGMENTS = 12
 TICKS = 10000
 CHUNK = 1000
-PLACEMENT_TRIALS = 16           # candidate row buffers Engine.plan times the sampler on before keeping one (untimed set-up)
 VELOCITY, DT, F = 3.0, 0.01, 10
 FP64_WAVE_INSTR_PEAK = 39.3e12 / 64  # vector fp64 peak of MI355X_MICROARCH.md: 78.6 TFLOP/s = 39.3 T lane-FMA/s = 614 G wave-instr/s
 GATHER_TIMEOUT_S = 240
@@ -288,10 +287,9 @@ def main():
     B, m = args.batch, SEGMENTS
     eng = Engine(dev)
     wps = missions(B * world, m, rank * B, (rank + 1) * B)
-    # The row buffer is chosen among PLACEMENT_TRIALS allocations by timing the sampler on each (Engine.plan, DESIGN K2: whether
-    # the rows stream out at ~6.0 or ~5.1 TB/s is a property of where the buffer lies, for as long as it lives).  Untimed
-    # set-up, reported in the line.
-    plan = eng.plan(wps, VELOCITY, DT, placement_trials=1)          # allocates (first allocation, no search); also the first warm-up
+    # The row buffer is the FIRST allocation: no placement search (the streaming sampler's time does not depend on where its
+    # buffer lies, DESIGN K2).
+    plan = eng.plan(wps, VELOCITY, DT)                               # allocates; also the first warm-up
     fleet = eng.fleet(plan)
     log = torch.empty((CHUNK, 13, B), dtype=torch.float64, device=dev)
     n_chunks = TICKS // CHUNK
@@ -315,17 +313,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The planning chain into the FIRST allocation of the row buffer -- what a caller gets who does not search -- measured
-    # in the same context as the timed steps (one chain per step, between rollouts); then the search (untimed set-up: keeps
-    # the fastest candidate, stops at the first one of the fast kind).
-    first_rec = []
-    for _ in range(2):
-        one_step()
-    for _ in range(4):
-        one_step(first_rec)
-    torch.cuda.synchronize()
-    plan_first_alloc_s = float(np.mean([a.elapsed_time(b) for a, b, _ in first_rec])) * 1e-3
-    eng.place_rows(plan, PLACEMENT_TRIALS)
     for _ in range(args.warmup):
         one_step()
     rec = []
@@ -411,17 +398,13 @@ def main():
                          "rollout_source_sha": rollout_source_sha()},
             "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
                         "ms_solve_plus_sample": plan_avg_s * 1e3,
-                        "ms_solve_plus_sample_first_allocation": plan_first_alloc_s * 1e3,
-                        "value_first_allocation": B * m / plan_first_alloc_s,
-                        "frac_first_allocation": plan.algorithmic_bytes / plan_first_alloc_s / 1e9 / HBM_PEAK_GBS,
+                        "row_buffer": "first allocation (Engine.plan's default: no placement search)",
+                        "frac_first_allocation": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
                         "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes": plan.algorithmic_bytes},
-                        "row_buffer_placement": {"trials": PLACEMENT_TRIALS,
-                                                 "sampler_ms_per_candidate": [round(float(t), 4) for t in (plan.placement_ms or [])],
-                                                 "note": "untimed set-up: the row buffer kept is the candidate allocation "
-                                                         "the sampler streams into fastest (DESIGN K2)"}},
+                        },
             "rollout_only": {"value": B * CHUNK / roll_avg_s, "unit": "UAV control-steps/s per GPU",
                              "note": "SURVEY 8(d)(i): B x K / time of the rollout launches alone (`value` above also "
                                      "carries the planning time of every step)"},
@@ -450,6 +433,21 @@ def main():
                 pairs.append((a, b))
             torch.cuda.synchronize()
         per_launch = [a.elapsed_time(b) for a, b in pairs]
+        # the sampler alone on the bench's row buffer, both kernels: the default (chunk-streaming, 4 waves per workgroup) and
+        # the one-wave-per-mission kernel, whose time depends on where the buffer lies
+        sampler_ms = {}
+        for label, waves in (("chunk_streaming_w4", 4), ("one_wave_per_mission", 1)):
+            eng.ctx.set_option("sampler_waves", waves)
+            for _ in range(3):
+                eng.sample(plan)
+            a, b = ev(), ev()
+            a.record()
+            for _ in range(5):
+                eng.sample(plan)
+            b.record()
+            torch.cuda.synchronize()
+            sampler_ms[label] = round(a.elapsed_time(b) / 5, 4)
+        eng.ctx.set_option("sampler_waves", 4)
         # the same missions flown at half the speed (velocity 1.5: legs demand < 2.5 m/s^2): nobody departs
         slow = eng.plan(wps, VELOCITY / 2, DT, placement_trials=1)
         fl2 = eng.fleet(slow)
@@ -466,6 +464,7 @@ def main():
         kept2 = float(((fl2.X[0:3] - tgt2).norm(dim=0) < 0.5).double().mean())
         if rank == 0:
             out["roofline"]["per_launch_ms_one_step"] = [round(x, 4) for x in per_launch]
+            out["minsnap"]["sampler_ms_on_this_row_buffer"] = sampler_ms
             out["rollout_only_flyable"] = {"value": B * CHUNK * n_chunks / (a.elapsed_time(b) * 1e-3),
                                            "unit": "UAV control-steps/s per GPU", "velocity": VELOCITY / 2,
                                            "frac_uavs_within_0.5m_of_target_row": kept2,

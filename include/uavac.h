@@ -112,9 +112,11 @@ const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
  * wave.  "lds_pad": extra LDS bytes per rollout workgroup (caps the workgroups a CU takes; 0).
  * "idle_waves": -1 (default: chosen per launch), 0, 1 = a placeholder wave between the compute and the
  * store wave of every rollout workgroup, which lets two workgroups on a CU occupy all four SIMDs
- * (16 385 .. 32 768 UAVs).  "sampler_waves": 1 (default), 4, 8, 16 = wavefronts per mission of the
- * plain sampler (the multi-wave kernel is bit-identical and slower; kept for comparison).
- * Defaults from the environment (UAVAC_ROLLOUT_ALIGN, UAVAC_YAW_GROUP) at uavac_create.
+ * (16 385 .. 32 768 UAVs).  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
+ * chunk-streaming sampler, "sampler_group": 1 (default) .. 64 = consecutive missions per workgroup;
+ * "sampler_waves" 1 = the one-wave-per-mission sampler (same rows bit for bit; faster into some row
+ * buffers, slower into most: DESIGN K2).
+ * Defaults from the environment (UAVAC_ROLLOUT_ALIGN, UAVAC_YAW_GROUP, UAVAC_SAMPLER_WAVES, UAVAC_SAMPLER_GROUP) at uavac_create.
  * ONE option is not a tuning knob but part of the log layout: "log_pitch" = P doubles per log row,
  * 0 (default) = B.  With P >= B the rollouts write state_log [K][13][P] and cmd_log [K][12][P]
  * (columns B .. P-1 are never touched).  Rows of a multiple of 16 doubles start on 128-byte lines

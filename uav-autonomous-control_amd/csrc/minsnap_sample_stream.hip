@@ -212,6 +212,8 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
             // ---- the carry: wait for the item before (ordering of the mailboxes; its values only inside a mission)
             bool c_has = false;
             double c_ang = 0.0, c_sum = 0.0, c_first = 0.0;
+            // (the hand-over is the one serial piece of a workgroup: it runs ahead of the other waves of its SIMD)
+            __builtin_amdgcn_s_setprio(2);
             if (i > 0) {
                 const unsigned src = lds_address(&mail[w == 0 ? W - 1 : w - 1]);
                 int seq, has;
@@ -244,6 +246,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
             const double m_first = c_has ? c_first : (mask != 0ull ? first_ang : 0.0);
             if (lane == 0)
                 mail_write(lds_address(&mail[w]), i + 1, (c_has || mask != 0ull) ? 1 : 0, mask != 0ull ? last_ang : c_ang, run, m_first);
+            __builtin_amdgcn_s_setprio(0);
             // ---- the rows with their history
             const bool prev_has = prev_in || c_has;
             const double prev_ang = prev_in ? prev_ang_in : c_ang;
@@ -301,7 +304,7 @@ template <int W, bool HITS, bool DERIVS, bool RAGGED>
 int launch_stream(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets, int B, int m,
                   double dt, double *traj, const SampleExtras &x, int G) {
     size_t lds = stream_lds_bytes(W, G, m);
-    while (G > 1 && lds > 64 * 1024) lds = stream_lds_bytes(W, --G, m);
+    while (G > 1 && lds > 150 * 1024) lds = stream_lds_bytes(W, --G, m);
     auto kern = minsnap_sample_stream_kernel<W, HITS, DERIVS, RAGGED>;
     if (lds > 64 * 1024) UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // chunk starts on 128-byte lines: (address / 8 + 11 * rho) % 16 == 0 for chunk starts at rows rho (mod 64) -> rho = 13 a % 16
@@ -334,6 +337,7 @@ int launch_stream_w(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_row
 int uavac_launch_sample_stream(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets, int B,
                                int m, double dt, double *traj, const SampleExtras &x, int waves, int group) {
     if (group < 1) group = 1;
+    if (waves == 2) return launch_stream_w<2>(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x, group);
     if (waves == 4) return launch_stream_w<4>(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x, group);
     if (waves == 16) return launch_stream_w<16>(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x, group);
     return launch_stream_w<8>(ctx, coeffs, seg_rows, row_offsets, B, m, dt, traj, x, group);

@@ -239,7 +239,7 @@ int uavac_create(uavac_ctx **out, int device_id) {
     }
     if (const char *e = getenv("UAVAC_YAW_GROUP")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 16) ctx->yaw_group = v; }
     if (const char *e = getenv("UAVAC_ROLLOUT_ALIGN")) ctx->rollout_align = (e[0] == '0') ? 0 : 1;
-    if (const char *e = getenv("UAVAC_SAMPLER_WAVES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 8 || v == 16) ctx->sampler_waves = v; }
+    if (const char *e = getenv("UAVAC_SAMPLER_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->sampler_waves = v; }
     if (const char *e = getenv("UAVAC_SAMPLER_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) ctx->sampler_group = v; }
     {
         int cus = 0;
@@ -295,7 +295,7 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
         if (value != 1 && value != 4 && value != 8 && value != 16) return uavac_fail(ctx, UAVAC_EINVAL, "yaw_group is 1, 4, 8 or 16");
         ctx->yaw_group = value;
     } else if (n == "sampler_waves") {
-        if (value != 1 && value != 4 && value != 8 && value != 16) return uavac_fail(ctx, UAVAC_EINVAL, "sampler_waves is 1, 4, 8 or 16");
+        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return uavac_fail(ctx, UAVAC_EINVAL, "sampler_waves is 1, 2, 4, 8 or 16");
         ctx->sampler_waves = value;
     } else if (n == "sampler_group") {
         if (value < 1 || value > 64) return uavac_fail(ctx, UAVAC_EINVAL, "sampler_group is 1 .. 64");

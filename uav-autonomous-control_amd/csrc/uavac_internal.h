@@ -30,7 +30,7 @@ struct uavac_ctx {
     size_t pin_cap = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::string err;
-    int sampler_waves = 4;           // tuning: wavefronts per workgroup of the sampler: 4, 8, 16 (minsnap_sample_stream.hip); 1 = one wave per mission (minsnap_sample.hip)
+    int sampler_waves = 4;           // tuning: wavefronts per workgroup of the sampler: 2, 4, 8, 16 (minsnap_sample_stream.hip); 1 = one wave per mission (minsnap_sample.hip)
     int sampler_group = 1;           // tuning: consecutive missions per workgroup of the streaming sampler
     int yaw_group = 8;               // tuning: chunks of the sampler's dense yaw column that leave together (1, 4, 8, 16)
     int rollout_align = 1;           // tuning: launch the 2-wave aligner kernel before a logged launch of shape 1

@@ -151,8 +151,7 @@ class RRTDeviceBatch:
 
 class Engine:
     """One GPU, one `uavac_ctx`.  Kernels are enqueued on torch's current stream for that device."""
-    FAST_ROW_BUFFER_BYTES_PER_S = 5.6e12       # `place_rows`: a row buffer the sampler fills at this rate is of the fast kind
-    DEFAULT_PLACEMENT_TRIALS = 4               # `plan`: candidates tried for large row buffers when the caller does not say
+    FAST_ROW_BUFFER_FRACTION_OF_PEAK = 0.70    # `place_rows`: a row buffer the sampler fills at this share of the device's HBM peak is of the fast kind
 
     def __init__(self, device=None):
         torch = _torch()
@@ -182,18 +181,17 @@ class Engine:
 
     # -- planning ---------------------------------------------------------------
     def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True, dense_yaw: bool = False,
-             placement_trials: int = None) -> Plan:
+             placement_trials: int = 1) -> Plan:
         """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124).
         `strict`: raise UavacError(ESINGULAR) when a mission's knot system is singular (a repeated waypoint) instead of
         returning NaN coefficients for it; with strict=False inspect `plan.status`.
         `dense_yaw`: also keep the yaw column on its own (`plan.yaw`, 8 B per row).  Not needed to fly the plan: the
         plan-fed rollout scans the yaw itself from `plan.first_yaw` (8 B per mission).
-        `placement_trials` > 1: where the row buffer lies in HBM decides whether the sampler streams into it at ~6.0 or at
-        ~5.1 TB/s -- a property of the allocation that lasts as long as the buffer (tools/buffer_placement_probe.py, DESIGN
-        K2).  So allocate up to that many candidate buffers one after the other, time the sampler on each, stop at the first
-        one the rows stream into at >= 5.6 TB/s (the fast kind), keep the fastest and free the others (`plan.placement_ms`
-        holds the times).  1 = take the first allocation.  Default (None): 4 for row buffers of 1 GiB and more when the GPU
-        has room for the candidates side by side (where the effect is worth ~15 % of every later `replan`), else 1."""
+        `placement_trials` > 1 (opt-in; default 1 = take the first allocation): time the sampler on up to that many
+        candidate row buffers and keep the fastest (`place_rows`).  Only the one-wave-per-mission sampler
+        (`ctx.set_option("sampler_waves", 1)`) cares where its row buffer lies (1.25-1.33 ms into some allocations, 1.47-1.50
+        into others for the bench's 7.5 GB of rows); the default chunk-streaming sampler takes 1.34-1.40 ms into any of them
+        (DESIGN K2), so the default is no search."""
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -217,15 +215,19 @@ class Engine:
         first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
         plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw, first_yaw)
         self.sample(plan)
-        if placement_trials is None:
-            row_bytes = total * nat.TRAJ_COLS * 8
-            free = torch.cuda.mem_get_info(self.device)[0] if row_bytes >= (1 << 30) else 0
-            placement_trials = self.DEFAULT_PLACEMENT_TRIALS if (row_bytes >= (1 << 30) and free > 4 * row_bytes) else 1
         if int(placement_trials) > 1 and total > 0:
             self.place_rows(plan, int(placement_trials))
         if strict:
             self.check(plan)
         return plan
+
+    def hbm_peak_bytes_per_s(self) -> float:
+        """The device's HBM peak from its own properties (memory clock x bus width x 2, DDR): 8.0e12 on MI355X."""
+        p = self._torch.cuda.get_device_properties(self.device)
+        clock_khz = getattr(p, "memory_clock_rate", 0) or 0
+        width_bits = getattr(p, "memory_bus_width", 0) or 0
+        peak = 2.0 * clock_khz * 1e3 * width_bits / 8.0
+        return peak if peak > 1e11 else 8.0e12
 
     def place_rows(self, plan: Plan, trials: int):
         """Optional: choose `plan.traj` among up to `trials` candidate allocations by timing the sampler on each (see `plan`)."""
@@ -249,7 +251,7 @@ class Engine:
         # first candidate the rows stream into at >= 5.6 TB/s -- the fast group -- and otherwise keep the fastest of all.
         # (Round 2 stopped at "7 % below the slowest seen", which a still slower outlier satisfied for a slow buffer.)
         row_bytes = float(plan.total_rows) * nat.TRAJ_COLS * 8.0
-        fast_ms = row_bytes / self.FAST_ROW_BUFFER_BYTES_PER_S * 1e3
+        fast_ms = row_bytes / (self.FAST_ROW_BUFFER_FRACTION_OF_PEAK * self.hbm_peak_bytes_per_s()) * 1e3
         candidates, times = [plan.traj], [timed(plan.traj)]
         while len(candidates) < trials and min(times) > fast_ms:
             try:
