@@ -100,6 +100,38 @@ def kept_measurement(name, key, kernel=None):
     return rec.get(key)
 
 
+PLANNING_SOURCES = ("csrc/minsnap_sample_stream.hip", "csrc/minsnap_solve_bt.hip", "csrc/minsnap_solve.hip", "csrc/minsnap_eval.h",
+                    "csrc/minsnap_yaw.h")
+
+
+def planning_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in PLANNING_SOURCES:
+        with open(os.path.join(PKG, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def planning_traffic():
+    """Counter bytes of one planning chain (K1 solve + K2 sampler) from profiles/hbm_traffic.json, or None when the planning
+    kernels' sources have changed since they were collected."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if rec.get("planning_source_sha") != planning_source_sha():
+        return None
+    a, b = rec.get("minsnap_sample_bytes_per_launch"), rec.get("minsnap_solve_bytes_per_launch")
+    return (a + b) if (a is not None and b is not None) else None
+
+
+def nat_build_info():
+    from uav_ac import _native as nat
+    return nat.lib().uavac_build_info().decode()
+
+
 def cpu_baseline(eng=None, wps=None):
     """The CPU oracle (test infrastructure; here only as the timed baseline and as the checker, never as
     product) on a bounded sample of the same workload: plan + TICKS control ticks for a few missions.  When an
@@ -368,6 +400,7 @@ def main():
         same_size = B == B_PER_GPU
         traffic = kept_measurement("hbm_traffic.json", "control_rollout_bytes_per_launch", kernel_name) if same_size else None
         valu = kept_measurement("hbm_traffic.json", "control_rollout_valu_wave_insts_per_launch", kernel_name) if same_size else None
+        plan_traffic = planning_traffic() if same_size else None
         out = {
             "metric": "UAV control-steps/sec at batch=65536",
             "value": value,
@@ -394,8 +427,13 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("profiles/hbm_traffic.json (tools/pmc_traffic.py; same kernel sources)"
                                             if traffic is not None else None),
+                         # the same launch priced by the bytes the counters saw it move (WRITE_SIZE + 2 x FETCH_SIZE): the plan-fed
+                         # kernel evaluates its target rows instead of reading them, so it moves less than the algorithmic figure
+                         "frac_counter_bytes": (traffic / roll_avg_s / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
                          "algorithmic_bytes_per_launch": roll_bytes, "avg_launch_ms": roll_avg_s * 1e3,
+                         "kernel_vgprs": eng.ctx.last_rollout_vgprs(),
                          "rollout_source_sha": rollout_source_sha()},
+            "build": nat_build_info(),
             "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
                         "ms_solve_plus_sample": plan_avg_s * 1e3,
                         "row_buffer": "first allocation (Engine.plan's default: no placement search)",
@@ -403,7 +441,12 @@ def main():
                         "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
-                                     "algorithmic_bytes": plan.algorithmic_bytes},
+                                     "algorithmic_bytes": plan.algorithmic_bytes,
+                                     "traffic": plan_traffic,
+                                     "frac_counter_bytes": (plan_traffic / plan_avg_s / 1e9 / HBM_PEAK_GBS)
+                                     if plan_traffic is not None else None,
+                                     "traffic_source": ("profiles/hbm_traffic.json: K1 + K2 counter bytes per planning chain "
+                                                        "(same sampler / solver sources)") if plan_traffic is not None else None},
                         },
             "rollout_only": {"value": B * CHUNK / roll_avg_s, "unit": "UAV control-steps/s per GPU",
                              "note": "SURVEY 8(d)(i): B x K / time of the rollout launches alone (`value` above also "

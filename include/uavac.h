@@ -103,6 +103,13 @@ int uavac_device(const uavac_ctx *ctx);
  * plan-fed> of the rollout kernel the ctx launched last ("" before the first): what a profile of
  * the same call will show.  Diagnostics for benchmarks; the string lives in the ctx. */
 const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
+/* Vector registers per lane of that kernel in the loaded code object (hipFuncGetAttributes; 0 = unknown).  The rollout
+ * kernels must stay within 256: two wavefronts of the kernel share a SIMD (compute + store wave), and at 258 a launch ran
+ * 1.96 ms instead of 1.27 ms.  __graft_entry__.build() refuses a build that crosses the line; this is the same number seen
+ * from the running process. */
+int uavac_last_rollout_vgprs(const uavac_ctx *ctx);
+/* "libuavac <version>; gfx950; HIP <x.y.z>; <compiler version>" of the build (static string). */
+const char *uavac_build_info(void);
 /* Tuning knobs; results never depend on them (tested bit for bit).  "rollout_align": 1 (default) =
  * precede a rollout launch that writes a log by an empty kernel of the same workgroup shape (one
  * compute + one store wave), which makes the hardware place one wave of each kind on every SIMD
@@ -243,9 +250,14 @@ int uavac_minsnap_sample_ragged_dev(uavac_ctx *ctx, const double *coeffs, const 
  *     left as it is: active[b] = 0, overflow[b] = 1; a mission that received midpoints: touched[b] = 1, stays active;
  *   - counters [4] i32 (device): missions still active, missions that outgrew UAVAC_MAX_SEGMENTS in this round, the largest segment
  *     count after the round (a valid max_m for the next one), the segment total of the batch after the round.
- * max_m >= every mission's segment count, <= UAVAC_MAX_SEGMENTS.  Scratch (device, caller-owned, S_cap >= the segment
- * total before the round): times [S_cap], seg_rows [S_cap] i32, row_offsets [B+1], coeffs [S_cap][8][3], hit [S_cap] i32;
- * wp_out holds S_cap_next + B waypoints with S_cap_next >= the segment total after the round (at most twice the one before). */
+ * max_m >= every mission's segment count, <= UAVAC_MAX_SEGMENTS.  SCRATCH (device, caller-owned, sizes TRUSTED -- the call
+ * cannot check them; S_cap >= the segment total before the round): times [S_cap], seg_rows [S_cap] i32, row_offsets [B+1],
+ * coeffs [S_cap][8][3], hit [S_cap] i32.  They are scratch in the strict sense: what they hold after the call is valid only
+ * for the missions that were active IN THIS ROUND (waves without an active mission skip the solve while the segment offsets
+ * move from round to round): do not sample from them -- plan the final waypoints with uavac_minsnap_*_ragged_dev.  wp_out
+ * holds S_cap_next + B waypoints with S_cap_next >= the segment total after the round (at most twice the one before, and
+ * never more than B * UAVAC_MAX_SEGMENTS).  A singular knot system (repeated waypoint) raises sticky flag 1; its mission's
+ * positions are NaN, inside no cuboid: it leaves the loop as if collision-free -- check uavac_take_flags. */
 int uavac_minsnap_obstacle_round_dev(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, int max_m,
                                      double velocity, double dt, const double *aabb, int32_t *active, int32_t *overflow,
                                      int32_t *touched, double *wp_out, int64_t *seg_offsets_out, int32_t *counters,
@@ -258,7 +270,8 @@ int uavac_minsnap_obstacle_round_dev(uavac_ctx *ctx, const double *wp, const int
  * it has and is reported in converged [B] (0; may be NULL).  recheck_passes > 0 sweeps the missions that received midpoints
  * over the obstacle list again (beyond the reference).  Output: the final waypoints wp_out [seg_offsets_out[B] + B][3]
  * (wp_capacity rows available; B * (UAVAC_MAX_SEGMENTS + 1) always suffice; UAVAC_EINVAL with seg_offsets_out filled in when
- * it is too small) -- sample them with uavac_minsnap_plan_ragged to get get_trajectory()'s rows. */
+ * it is too small) -- sample them with uavac_minsnap_plan_ragged to get get_trajectory()'s rows.  UAVAC_ESINGULAR (outputs
+ * complete): some mission has a repeated waypoint; its collision scan was void. */
 int uavac_minsnap_obstacle_waypoints(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, int B, double velocity,
                                      double dt, const double *cuboids, int n_cuboids, int max_iterations, int recheck_passes,
                                      double *wp_out, int64_t wp_capacity, int64_t *seg_offsets_out, int32_t *converged);

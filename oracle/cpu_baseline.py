@@ -36,6 +36,26 @@ def effective_cpus():
     return n, note
 
 
+def cpu_model():
+    """Model string of the host CPU (stated next to the core count)."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def blas_threads():
+    """The thread settings a NumPy / BLAS baseline would run under.  The C oracle itself links no BLAS (its
+    solve is its own scalar LU), so they do not change its rate; they are stated because the reference's NumPy path does."""
+    import os
+    return {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+
+
 def _all_cores(wps, V, segments, ticks, velocity, dt, budget_s):
     """The same scalar work on every CPU this process owns at once: POSIX threads inside the C library, each
     planning and flying whole missions with its own buffers (no Python in the loop, no fork from a process that
@@ -73,6 +93,9 @@ def run(segments: int, ticks: int, velocity: float, dt: float, budget_s: float =
         "unit": "UAV control-steps/s",
         "cores": 1,
         "kind": "port",
+        "cpu_model": cpu_model(),
+        "blas_threads": blas_threads(),
+        "blas_note": "the C oracle links no BLAS (own scalar LU): these settings do not change its rate",
         "sample": f"{n} missions of the same generator: plan ({segments} segments, {rows} rows) + {ticks} ticks each, "
                   f"scalar C oracle (gcc -O2), {total:.1f} s of CPU",
         "control_only_steps_per_s": n * ticks / t_roll,

@@ -176,8 +176,8 @@ def test_pitched_logs_equal_dense_logs_and_leave_the_padding_alone(eng, B):
     P = -(-B // 16) * 16 + 48
     ps = torch.full((K, 13, P), -5.0, dtype=torch.float64, device=eng.device)
     pc = torch.full((K, 12, P), -5.0, dtype=torch.float64, device=eng.device)
-    s_view, c_view = f1.rollout(K, state_log=ps, cmd_log=pc)
-    assert s_view.data_ptr() == ps.data_ptr()
+    s_view, c_view = f1.rollout(K, state_log=ps, cmd_log=pc, log_pitch=P)      # pitched caller buffers are opt-in
+    assert s_view.data_ptr() == ps.data_ptr() and s_view.shape == (K, 13, B) and c_view.shape == (K, 12, B)
     assert torch.equal(ps[:, :, :B], dense_s) and torch.equal(pc[:, :, :B], dense_c)
     assert bool((ps[:, :, B:] == -5.0).all()) and bool((pc[:, :, B:] == -5.0).all())
     assert torch.equal(f0.state, f1.state) and torch.equal(f0.istate, f1.istate)
@@ -186,6 +186,26 @@ def test_pitched_logs_equal_dense_logs_and_leave_the_padding_alone(eng, B):
     s2, c2 = f2.rollout(K, state_log=True, cmd_log=True)
     assert s2.shape == (K, 13, B) and s2.stride(1) % 16 == 0
     assert torch.equal(s2, dense_s) and torch.equal(c2, dense_c)
+    # round-3 ADVICE: a caller's tensor is written densely whatever its shape (the pitch is never inferred from it), ...
+    f3 = eng.fleet(plan, from_plan=False)
+    wide = torch.full((K, 13, P), -5.0, dtype=torch.float64, device=eng.device)
+    f3.rollout(K, state_log=wide)
+    assert torch.equal(wide.reshape(-1)[:K * 13 * B].view(K, 13, B), dense_s) and bool((wide.reshape(-1)[K * 13 * B:] == -5.0).all())
+    # ... a log allocated beside a caller's dense one takes the same pitch instead of being refused (B % 16 != 0 too), ...
+    f4 = eng.fleet(plan, from_plan=False)
+    mine = torch.empty((K, 12, B), dtype=torch.float64, device=eng.device)
+    s4, c4 = f4.rollout(K, state_log=True, cmd_log=mine)
+    assert s4.shape == (K, 13, B) and s4.is_contiguous() and c4 is mine
+    assert torch.equal(s4, dense_s) and torch.equal(mine, dense_c)
+    # ... and beside a pitched one as well
+    f5 = eng.fleet(plan, from_plan=False)
+    pc2 = torch.full((K, 12, P), -5.0, dtype=torch.float64, device=eng.device)
+    s5, c5 = f5.rollout(K, state_log=True, cmd_log=pc2, log_pitch=P)
+    assert s5.shape == (K, 13, B) and s5.stride(1) == P and torch.equal(s5, dense_s) and torch.equal(c5, dense_c)
+    with pytest.raises(ValueError):
+        f5.rollout(K, state_log=dense_s, log_pitch=B + 16)          # too small for that pitch
+    with pytest.raises(ValueError):
+        f5.rollout(K, state_log=True, log_pitch=B - 1)
     # a pitch below B is refused
     eng.ctx.set_option("log_pitch", B - 1)
     try:

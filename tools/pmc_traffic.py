@@ -24,11 +24,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import B_PER_GPU, CHUNK, F, rollout_source_sha  # noqa: E402
+from bench import B_PER_GPU, CHUNK, F, planning_source_sha, rollout_source_sha  # noqa: E402
 
 OUT = os.path.join(ROOT, "gpurun_out")
-TAG = os.environ.get("UAVAC_PROFILE_TAG", "r03")          # round tag of the files written
-KERNELS = {"control_rollout": "control_rollout_kernel", "minsnap_sample": "minsnap_sample_kernel",
+TAG = os.environ.get("UAVAC_PROFILE_TAG", "r04")          # round tag of the files written
+KERNELS = {"control_rollout": "control_rollout_kernel", "minsnap_sample": "minsnap_sample_stream_kernel",
            "minsnap_solve": "minsnap_solve_bt_kernel"}
 
 
@@ -63,6 +63,7 @@ def main():
                      "on `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-config4 --no-extras`",
            "units": "WRITE_SIZE / FETCH_SIZE are KiB; bytes = value * 1024; FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B); SQ_INSTS_VALU is a plain count (the CSV column name says KiB for all rows)",
            "rollout_source_sha": rollout_source_sha(),
+           "planning_source_sha": planning_source_sha(),
            "git": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None}
     rows = [["kernel", "counter", "dispatches", "mean_value_KiB", "min_KiB", "max_KiB"]]
     for (key, name), vals in sorted(w.items()):

@@ -43,7 +43,7 @@ for B in [int(x) for x in args.sizes.split(",")]:
         eng.ctx.set_option("idle_waves", idle)
         fleet = eng.fleet(plan, from_plan=(feed == "plan"))
         for _ in range(3):
-            fleet.rollout(K, state_log=log)
+            fleet.rollout(K, state_log=log, log_pitch=pitch)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best = 1e9
@@ -51,7 +51,7 @@ for B in [int(x) for x in args.sizes.split(",")]:
             fleet.reset()
             a.record()
             for _ in range(5):
-                fleet.rollout(K, state_log=log)
+                fleet.rollout(K, state_log=log, log_pitch=pitch)
             b.record()
             torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b) / 5)

@@ -594,6 +594,14 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
              tf(GR), tf(YS));
     ctx->last_rollout = name;
+    // vector registers of that kernel as the loaded code object has them (once per variant): above 256 a SIMD holds ONE
+    // wave of it and the launch runs at 0.65x -- a toolchain that crosses the line shows up here and in bench.py's line
+    static int vgprs = -1;
+    if (vgprs < 0) {
+        hipFuncAttributes fa;
+        vgprs = hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess ? fa.numRegs : 0;
+    }
+    ctx->last_rollout_vgprs = vgprs;
 }
 
 template <bool LS, bool LC, bool AB>

@@ -11,11 +11,13 @@
 
 namespace {
 
-constexpr size_t kStageChunk = (size_t)1 << 20;       // bytes per half of the pinned ping-pong buffer
-// Transfers up to this size go through the ctx's own pinned buffer (no pinning work inside the runtime, no allocation);
-// larger ones are handed to hipMemcpyAsync as they are: the runtime's pageable path moves them at 50 GB/s aggregate
-// (H2D + D2H of a 4 096-UAV rollout, tools/host_path_rate.py), a single-threaded copy through a staging buffer at 27.
+constexpr size_t kStageChunk = (size_t)256 << 10;     // bytes per half of the pinned ping-pong buffer
+// Transfers up to this size go through the ctx's own pinned buffer (no pinning work inside the runtime, no allocation), up
+// to four pieces with the DMA of one overlapping the CPU copy of its neighbour; larger ones are handed to hipMemcpyAsync as
+// they are: the runtime's pageable path moves them at 50 GB/s aggregate (H2D + D2H of a 4 096-UAV rollout,
+// tools/host_path_rate.py), a single-threaded copy through a staging buffer at 27.
 constexpr size_t kStageLimit = (size_t)1 << 20;
+static_assert(kStageLimit >= 2 * kStageChunk, "the ping-pong needs transfers of more than one piece to overlap anything");
 
 // Host <-> device copies of the host-pointer twins.  The caller's buffers are pageable; they travel through the ctx's
 // pinned staging buffer in kStageChunk pieces, two halves in flight: the DMA of one piece overlaps the CPU copy of the
@@ -319,6 +321,15 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
 }
 
 const char *uavac_last_rollout_kernel(const uavac_ctx *ctx) { return ctx ? ctx->last_rollout.c_str() : ""; }
+
+int uavac_last_rollout_vgprs(const uavac_ctx *ctx) { return ctx ? ctx->last_rollout_vgprs : UAVAC_EINVAL; }
+
+#define UAVAC_STR2(x) #x
+#define UAVAC_STR(x) UAVAC_STR2(x)
+const char *uavac_build_info(void) {
+    return "libuavac " UAVAC_STR(UAVAC_VERSION) "; gfx950; HIP " UAVAC_STR(HIP_VERSION_MAJOR) "." UAVAC_STR(HIP_VERSION_MINOR) "."
+           UAVAC_STR(HIP_VERSION_PATCH) "; " __VERSION__;
+}
 
 int uavac_take_flags(uavac_ctx *ctx, int32_t flags[4]) {
     UAVAC_ENTER(ctx);
@@ -794,6 +805,9 @@ int uavac_minsnap_obstacle_waypoints(uavac_ctx *ctx, const double *wp, const int
     if (int rc = d2h_staged(ctx, wp_out, wp_a, (size_t)n_wp * 24)) return rc;
     UAVAC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (converged) for (size_t b = 0; b < nB; ++b) converged[b] = failed[b] ? 0 : 1;
+    // a singular knot system (a repeated waypoint) gives NaN coefficients, and NaN positions are inside no cuboid: such a
+    // mission would pass for collision-free.  The outputs are complete, the call says so (like uavac_minsnap_solve).
+    if (fl[1]) return uavac_fail(ctx, UAVAC_ESINGULAR, "a mission's knot system is singular (repeated waypoint?): its collision scan is void");
     return UAVAC_OK;
 }
 

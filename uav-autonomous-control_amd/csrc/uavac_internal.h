@@ -40,6 +40,7 @@ struct uavac_ctx {
     int64_t log_pitch = 0;           // doubles per row of the rollout's logs; 0 = B (option "log_pitch")
     int n_simds = 1024;              // SIMDs of the device (4 per CU): the logged rollout launches one workgroup per SIMD at most
     std::string last_rollout;        // name and template arguments of the rollout kernel launched last (diagnostics)
+    int last_rollout_vgprs = 0;      // ... and its vector registers per lane (hipFuncGetAttributes); 0 = unknown
 };
 
 // Every entry point that launches, allocates or copies runs with the ctx's device current and puts the caller's

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "uavac_synchronize": (C.c_int, [_P]),
     "uavac_device": (C.c_int, [_P]),
     "uavac_last_rollout_kernel": (C.c_char_p, [_P]),
+    "uavac_last_rollout_vgprs": (C.c_int, [_P]),
+    "uavac_build_info": (C.c_char_p, []),
     "uavac_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "uavac_take_flags": (C.c_int, [_P, _P]),
     "uavac_vehicle_default": (None, [C.POINTER(Vehicle)]),
@@ -244,6 +246,9 @@ class Context:
 
     def last_rollout_kernel(self) -> str:
         return (lib().uavac_last_rollout_kernel(self._h) or b"").decode()
+
+    def last_rollout_vgprs(self) -> int:
+        return int(lib().uavac_last_rollout_vgprs(self._h))
 
 
 PILOT_CONTROLLER, PILOT_DYNAMICS = 1, 2

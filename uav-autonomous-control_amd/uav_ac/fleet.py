@@ -769,45 +769,47 @@ class Fleet:
                    int(self._hover), _ptr(self.state), _ptr(self.istate))
         self._plan_epoch = getattr(self.plan, "epoch", 0)        # the carried yaw scan starts afresh
 
-    def rollout(self, K: int, state_log=None, cmd_log=None, aabbs=None):
+    def rollout(self, K: int, state_log=None, cmd_log=None, aabbs=None, log_pitch: int = None):
         """K fused ticks.  state_log / cmd_log: None, True (allocate) or a preallocated tensor.
 
-        Returns (state_log (K,13,B) | None, cmd_log (K,12,B) | None).
+        Layout of the logs: rows are `pitch` doubles apart, [K][13 | 12][pitch], columns B .. pitch-1 never touched.
+        * A caller's tensor is written DENSELY ([K][rows][B] in its first K*rows*B elements, whatever its shape) unless
+          `log_pitch` says otherwise -- then it must hold K*rows*log_pitch elements (log_pitch >= B).  The pitch is never
+          inferred from a tensor's shape.
+        * A log allocated here (True) takes the pitch of the caller's other log, else `log_pitch`, else B rounded up to a
+          multiple of 16 (rows on 128-byte lines: B = 65 534 at pitch B streams at half the rate of 65 536).
+        Returns (state_log, cmd_log) as (K, rows, B) views of pitched buffers (the tensor itself for a caller's dense one), or
+        None for a log that was not asked for.
         """
         e, torch = self.engine, self.engine._torch
-        # Log rows are `pitch` doubles apart.  A log allocated here gets a pitch that is a multiple of 16 (rows on 128-byte
-        # lines: B = 65 534 at pitch B streams at half the rate of 65 536) and is returned as the (K, rows, B) view of it; a
-        # caller's 3-D tensor (K, rows, P >= B) is written with pitch P; anything else contiguous with pitch B.
-        views, pitch = {}, None
+        B = self.B
+        callers = any(t is not None and t is not True for t in (state_log, cmd_log))
+        if log_pitch is not None:
+            pitch = int(log_pitch)
+            if pitch < B:
+                raise ValueError(f"log_pitch must be >= B = {B}")
+        else:
+            pitch = B if callers else -(-B // 16) * 16
+        bufs, views = {}, {}
         for name, t, rows in (("state_log", state_log, 13), ("cmd_log", cmd_log, nat.CMD_COLS)):
             if t is None:
                 continue
             if t is True:
-                want = -(-self.B // 16) * 16
-                if pitch not in (None, want):
-                    raise ValueError("state_log and cmd_log must have the same row pitch")
-                pitch = want
                 t = torch.empty((K, rows, pitch), dtype=torch.float64, device=e.device)
-                views[name] = (t, t[:, :, :self.B])
-                continue
-            if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() < K * rows * self.B:
-                raise ValueError(f"{name} must be a contiguous float64 tensor with >= K*{rows}*B elements")
-            p_ = int(t.shape[2]) if (t.dim() == 3 and t.shape[1] == rows and t.shape[2] >= self.B and t.shape[0] >= K) else self.B
-            if pitch not in (None, p_):
-                raise ValueError("state_log and cmd_log must have the same row pitch")
-            pitch = p_
-            views[name] = (t, t)
-        state_log, state_view = views.get("state_log", (None, None))
-        cmd_log, cmd_view = views.get("cmd_log", (None, None))
-        pitched = pitch is not None and pitch != self.B
+            elif t.dtype != torch.float64 or not t.is_contiguous() or t.numel() < K * rows * pitch:
+                raise ValueError(f"{name} must be a contiguous float64 tensor with >= K*{rows}*{pitch} elements")
+            bufs[name] = t
+            dense_callers = pitch == B and (state_log if name == "state_log" else cmd_log) is not True
+            views[name] = t if dense_callers else t.reshape(-1)[:K * rows * pitch].view(K, rows, pitch)[:, :, :B]
+        pitched = pitch != B
         if pitched:
             e.ctx.set_option("log_pitch", pitch)
         try:
-            self._launch_rollout(K, state_log, cmd_log, aabbs)
+            self._launch_rollout(K, bufs.get("state_log"), bufs.get("cmd_log"), aabbs)
         finally:
             if pitched:                       # the option belongs to this call: other users of the ctx get pitch = B
                 e.ctx.set_option("log_pitch", 0)
-        return state_view, cmd_view
+        return views.get("state_log"), views.get("cmd_log")
 
     def _launch_rollout(self, K, state_log, cmd_log, aabbs):
         e, torch = self.engine, self.engine._torch
@@ -928,7 +930,10 @@ class RcclComm:
         """Enqueue the gather and return at once: (the trajectories are final when planning ends, so their gather can run
         beside the rollout instead of after it).  `stream`: a torch.cuda.Stream for the transfers; it first waits for
         what the current stream has enqueued so far (the kernels that produce `rows`).  Default: the current stream.
-        Returns a ticket for `gather_finish`; `rows` must not be written before that."""
+        Returns a ticket for `gather_finish`; `rows` must not be written before that.  The Engine's ctx is bound to the
+        caller's stream again on return.  Between `*_begin` and `gather_finish` fly and log on this Engine as you like, but do
+        NOT plan on it (`plan`, `replan`, `sample`, obstacle rounds): the root's re-sampling on the side stream and a planning
+        call on yours would share the ctx's scratch arrays."""
         e, torch = self.engine, self.engine._torch
         if not rows.is_cuda or rows.dtype != torch.float64 or rows.dim() != 2:
             raise ValueError("rows must be a 2-D float64 GPU tensor")
@@ -945,6 +950,7 @@ class RcclComm:
             e._bind_stream()
             e.ctx.call("uavac_gather_rows_dev", self._h, _ptr(rows), int(rows.shape[0]), int(rows.shape[1]),
                        (C.c_int64 * self.world)(*counts), int(dst), _ptr(out))
+        e._bind_stream()                                      # back on the caller's stream
         return (stream, out, counts, rows)
 
     def gather_plan(self, plan: Plan, dst: int = 0, traj=None):
@@ -957,8 +963,10 @@ class RcclComm:
         return self.gather_finish(self.gather_plan_begin(plan, dst, traj=traj))
 
     def gather_plan_begin(self, plan: Plan, dst: int = 0, stream=None, traj=None):
-        """Enqueue `gather_plan` and return at once (`stream`, ticket: as for `gather_rows_begin`; the root's re-sampling
-        is enqueued on that stream too, behind the receives).  `traj`: a preallocated row buffer for the root."""
+        """Enqueue `gather_plan` and return at once (`stream`, ticket, and what may run meanwhile: as for `gather_rows_begin`;
+        the root's re-sampling is enqueued on that stream too, behind the receives).  `traj`: a preallocated row buffer for
+        the root.  A ragged batch makes the root wait inside this call for the splines-per-mission column (it sizes the
+        segment table on the host); a uniform batch returns at once on every rank."""
         e, torch = self.engine, self.engine._torch
         if getattr(plan, "coeffs", None) is None or not plan.coeffs.is_cuda:
             raise ValueError("gather_plan takes a device-resident Plan, RaggedBatch or RaggedPlan with its batch")
@@ -1004,6 +1012,7 @@ class RcclComm:
                 else:
                     gathered = e.plan_from_parts(co, tm, sr, m, plan.velocity, plan.dt, total_rows=sum(row_counts), traj=traj)
             keep = (plan, per_mission)
+        e._bind_stream()                                      # back on the caller's stream
         return (stream, gathered, row_counts, keep)
 
     def gather_finish(self, ticket):
@@ -1014,6 +1023,14 @@ class RcclComm:
             e._bind_stream()
             e.ctx.call("uavac_comm_finish", self._h)
         e._bind_stream()                                      # back on the caller's stream
+        here = torch.cuda.current_stream(e.device)
+        if stream is not here and out is not None:
+            # the result was allocated under the side stream and is consumed on the caller's: tell the caching allocator
+            for t in ([out] if torch.is_tensor(out) else
+                      [getattr(out, k, None) for k in ("traj", "coeffs", "times", "seg_rows", "row_offsets", "first_yaw", "status",
+                                                       "seg_offsets")]):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(here)
         return out, counts
 
     def loopback(self, src):
@@ -1052,6 +1069,9 @@ def gather_plan(plan, dst: int = 0, group=None, comm: "RcclComm" = None, engine:
     if comm is not None and getattr(plan.coeffs, "is_cuda", False):
         return comm.gather_plan(plan, dst)
     import torch.distributed as dist
+    if not hasattr(plan, "m"):
+        raise ValueError("the host (gloo) path of gather_plan takes a Plan with one segment count for the batch; a ragged "
+                         "batch travels over RCCL only (RcclComm.gather_plan)")
     m = int(plan.m)
     host = lambda t, dt_: torch.as_tensor(np.asarray(t.cpu() if hasattr(t, "cpu") else t)).to(dt_).contiguous()   # noqa: E731
     co, _ = gather_rows(host(plan.coeffs, torch.float64).reshape(-1, 24), dst, group)
