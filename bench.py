@@ -271,6 +271,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="UAVs per GPU (default: config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] leg")
+    ap.add_argument("--equal-shards", action="store_true", help="configs[3]: equal blocks per rank instead of a smaller block for the gather's root")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed diagnostic passes (per-launch table, "
                                                              "flyable-distribution rate)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous + one JSON line, no GPU work (tests of the "
@@ -521,8 +522,12 @@ def main():
     if not args.no_config4:
         del plan, fleet, log
         torch.cuda.empty_cache()
-        from uav_ac.fleet import shard_bounds
-        lo4, hi4 = shard_bounds(C4_TOTAL, rank, world)          # contiguous blocks; any N (sizes differ by at most one)
+        from uav_ac.fleet import balanced_root_share, shard_bounds, shard_sizes
+        # contiguous blocks; rank 0 -- the root of the final gather, which takes everybody's rows into its HBM while it flies --
+        # gets a smaller block so that it finishes with its peers (a projection from one-GPU measurements: fleet.py)
+        root_share = balanced_root_share(C4_TOTAL, world, C4_TICKS, C4_SEGMENTS) if (world > 1 and not args.equal_shards) else None
+        sizes4 = shard_sizes(C4_TOTAL, world, root_share, 0)
+        lo4, hi4 = shard_bounds(C4_TOTAL, rank, world, root_share, 0)
         B4 = hi4 - lo4
         wps4 = missions(C4_TOTAL, C4_SEGMENTS, lo4, hi4)
         plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)
@@ -566,7 +571,8 @@ def main():
         torch.cuda.synchronize()
         c4 = {"workload": "BASELINE.json configs[3]: 262144 UAVs in total (strong scaling), 8-segment missions, plan + "
                           "5000 fused ticks (5 launches x 1000, state logged), trajectories gathered to rank 0",
-              "batch_total": C4_TOTAL, "batch_per_gpu": B4, "segments": C4_SEGMENTS, "ticks": C4_TICKS,
+              "batch_total": C4_TOTAL, "batch_per_gpu": B4, "shard_sizes": sizes4, "root_share": root_share,
+              "segments": C4_SEGMENTS, "ticks": C4_TICKS,
               "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
               "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel(),
               "rollout_ms": c4_fly * 1e3, "steps_per_s_rollout_only": C4_TOTAL * C4_TICKS / c4_fly,
@@ -618,7 +624,7 @@ def main():
                     ok = sum(counts) == gathered.shape[0] and bool((gathered[:own] == plan4.traj[:own]).all())
                     # every peer's block starts with its first mission's first waypoint, at rest
                     offs = np.concatenate([[0], np.cumsum(counts)])
-                    starts = [shard_bounds(C4_TOTAL, r, world)[0] for r in range(world)]
+                    starts = [shard_bounds(C4_TOTAL, r, world, root_share, 0)[0] for r in range(world)]
                     first = missions(C4_TOTAL, C4_SEGMENTS, 0, C4_TOTAL)[starts, 0, :]
                     got = gathered[torch.as_tensor(offs[:-1], device=dev), 0:3].cpu().numpy()
                     ok = ok and bool(np.array_equal(got, first))
@@ -698,6 +704,9 @@ def main():
                                 over_err, over_s = f"{type(exc).__name__}: {exc}", float("nan")
                             if rank == 0 and over_err is None:
                                 c4.update({k_ms: over_s * 1e3, k_ok: bool(same), k_rate: C4_TOTAL * C4_TICKS / over_s})
+                                if kind == "plan" and same:        # THE config-4 job: plan, fly, trajectories resident on rank 0
+                                    c4["end_to_end"] = {"form": "plan + 5000 ticks, the plan gathered and re-sampled on rank 0 beside the flight",
+                                                        "ms": over_s * 1e3, "steps_per_s": C4_TOTAL * C4_TICKS / over_s}
                         if rank == 0 and over_err is not None:
                             c4["overlap_error"] = f"{kind}: {over_err}"
                         if not everybody_fine(over_err):

@@ -119,7 +119,9 @@ const char *uavac_build_info(void);
  * wave.  "lds_pad": extra LDS bytes per rollout workgroup (caps the workgroups a CU takes; 0).
  * "idle_waves": -1 (default: chosen per launch), 0, 1 = a placeholder wave between the compute and the
  * store wave of every rollout workgroup, which lets two workgroups on a CU occupy all four SIMDs
- * (16 385 .. 32 768 UAVs).  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
+ * (16 385 .. 32 768 UAVs).  "coeff_dma": -1 (default: chosen per launch), 0, 1 = the plan-fed rollout brings a UAV's next
+ * segment into its coefficient tile through registers on the spot / by LDS-DMA an outer tick ahead (faster unless the chip
+ * is full; same bits).  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
  * chunk-streaming sampler, "sampler_group": 1 (default) .. 64 = consecutive missions per workgroup;
  * "sampler_waves" 1 = the one-wave-per-mission sampler (same rows bit for bit; faster into some row
  * buffers, slower into most: DESIGN K2).

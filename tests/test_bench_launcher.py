@@ -54,15 +54,25 @@ def test_world_size_must_match_gpus():
 @pytest.mark.parametrize("n", [2, 3])
 def test_rehearsal_ranks_through_the_self_launcher_plan_gather_equals_row_gather(n):
     """The whole N > 1 control flow on one GPU, started by bench.py itself: n ranks (gloo, sharing the GPU) plan and fly
-    their shares of BASELINE config 4 (three ranks: shards that differ in size); the rows AND the plan are gathered; rank 0
-    re-samples the peers' rows from the peers' coefficients and finds them bit-identical to the rows the peers sent."""
+    their shares of BASELINE config 4 -- a smaller block for rank 0, the root of the gather (round-3 VERDICT 2: uneven shards),
+    equal blocks with --equal-shards; the rows AND the plan are gathered; rank 0 re-samples the peers' rows from the peers'
+    coefficients and finds them bit-identical to the rows the peers sent."""
+    from uav_ac.fleet import balanced_root_share, shard_sizes
     r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-extras"], UAVAC_BENCH_REHEARSAL="1")
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == n and "REHEARSAL" in line and "gather_error" not in line
     c4 = line["config4"]
-    assert c4["batch_per_gpu"] == -(-262144 // n) and c4["gather_verified"] is True and c4["plan_gather_verified"] is True   # 3 ranks: 87382 + 2 x 87381
+    sizes = shard_sizes(262144, n, balanced_root_share(262144, n, 5000, 8), 0)
+    assert c4["shard_sizes"] == sizes and c4["batch_per_gpu"] == sizes[0] < min(sizes[1:]) and sum(sizes) == 262144
+    assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True
     assert c4["plan_gather_ms"] > 0 and c4["steps_per_s_with_plan_gather"] > 0
+    if n == 2:                                  # the same with equal blocks
+        r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--equal-shards"], UAVAC_BENCH_REHEARSAL="1")
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        c4 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["config4"]
+        assert c4["shard_sizes"] == [131072, 131072] and c4["root_share"] is None
+        assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True
 
 
 @pytest.mark.gpu

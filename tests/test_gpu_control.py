@@ -498,10 +498,21 @@ def test_plan_fed_rollout_equals_row_fed_rollout(eng):
         a, b, d = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False), eng.fleet(plan, from_plan=True, yaw_from="column")
         assert a.from_plan and not b.from_plan and d.from_plan
         la, ca = a.rollout(K, state_log=True, cmd_log=True)
-        assert eng.ctx.last_rollout_kernel().endswith("true, false, true>")          # plan-fed, free flight, yaw scan
+        # plan-fed, free flight, yaw scan; the chip is far from full: the next segment's coefficients arrive by LDS-DMA (9th argument)
+        assert eng.ctx.last_rollout_kernel().endswith("true, false, true, true>")
         lb, cb = b.rollout(K, state_log=True, cmd_log=True)
         ld, cd = d.rollout(K, state_log=True, cmd_log=True)
-        assert eng.ctx.last_rollout_kernel().endswith("true, false, false>")         # plan-fed, yaw from the dense column
+        assert eng.ctx.last_rollout_kernel().endswith("true, false, false, true>")   # plan-fed, yaw from the dense column
+        # the same through registers on the spot (what a full chip uses): the same bits
+        eng.ctx.set_option("coeff_dma", 0)
+        try:
+            for yaw_from in ("scan", "column"):
+                e = eng.fleet(plan, from_plan=True, yaw_from=yaw_from)
+                le, ce = e.rollout(K, state_log=True, cmd_log=True)
+                assert eng.ctx.last_rollout_kernel().endswith("true, false, true>" if yaw_from == "scan" else "true, false, false>")
+                assert torch.equal(le, lb) and torch.equal(ce, cb) and torch.equal(e.state[:26], b.state[:26]) and torch.equal(e.istate, b.istate)
+        finally:
+            eng.ctx.set_option("coeff_dma", -1)
         assert torch.equal(la, lb) and torch.equal(ca, cb) and torch.equal(la, ld) and torch.equal(ca, cd)
         assert torch.equal(a.state[:26], b.state[:26]) and torch.equal(a.istate, b.istate)
         assert torch.equal(d.state[:26], b.state[:26]) and torch.equal(d.istate, b.istate)

@@ -33,6 +33,18 @@
 #include <cmath>
 #include <cstdlib>
 
+#ifdef UAVAC_DIAG_STAMPS      // DIAGNOSTIC builds only (tools/tick_stamps_probe.py): where a tick's cycles go, per workgroup
+__device__ long long g_uavac_diag[8192 * 8];
+__device__ long long g_uavac_diag2[8192 * 4];
+#define DIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())
+extern "C" int uavac_diag_read(long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uavac_diag), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+extern "C" int uavac_diag_read2(long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uavac_diag2), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace {
 
 using namespace uavac_dev;
@@ -61,6 +73,38 @@ __device__ __forceinline__ void row_wait(RowRegs &r) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]), "+v"(r.q[4])::"memory");
 }
 template <class T> __device__ __forceinline__ void settle(T &x) { asm volatile("" : "+v"(x)); }
+
+// Plan-fed rollout: the 24 coefficients of a lane's NEXT segment travel from HBM straight into the lane's column of the wave's
+// LDS tile (LDS-DMA, global_load_lds_dwordx4: no registers, nothing to wait for here) -- issued when the cursor enters the
+// segment, needed one outer tick (F ticks) later.  Loaded through registers on the spot they cost the whole load latency at
+// every segment change of any lane of the wave (44 % of the outer ticks), and that latency grows with the chip's load: 1.1 k
+// cycles at 8 192 UAVs, 2.3 k at 32 768, 3 k at 49 152 (tools/tick_stamps_probe.py) -- it was the half-full chip's longer tick.
+// Tile layout [12][64][2] doubles (minsnap_eval.h, STRIDE 0): instruction p moves doubles 2p, 2p + 1 of every active lane; lane l
+// lands at M0 + offset + 16 l, and the instruction offset counts for the GLOBAL address and for the LDS address alike, so M0
+// advances by 1024 - 16 per instruction.  Masked-off lanes keep their column (tools/scratch/ldsdma_gather_probe.hip).
+// Like the row prefetch the loads are invisible to the compiler's vmcnt bookkeeping; `plan_loads_wait` covers them.
+__device__ __forceinline__ void coeffs_dma(const double *src, unsigned tile_lds_bytes) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:16\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:32\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:48\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:64\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:80\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:96\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:112\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:128\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:144\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:160\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:176"
+                 : : "v"(src), "s"(tile_lds_bytes) : "memory", "m0", "scc");
+}
+// the row count of the segment AFTER the one just entered: needed a whole segment later
+// ("+v": the load lands IN the loop-carried register; an output-only operand may get a register of its own and be copied
+// into the carried one right away, before the data has arrived)
+__device__ __forceinline__ void seg_rows_issue(int &r, const int32_t *p) {
+    asm volatile("global_load_dword %0, %1, off" : "+v"(r) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void plan_loads_wait(int &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory"); }
 
 __device__ __forceinline__ double row_col(const RowRegs &r, int c) {      // c is a compile-time constant
     const u32x4 q = r.q[c >> 1];
@@ -112,7 +156,7 @@ constexpr int poly_tile_doubles(bool yawscan) { return (24 + (yawscan ? 0 : 16))
 // functions (minsnap_yaw.h; the sampler sums the corrections in the same left-to-right order).  Rows before a mission's
 // first heading take P.first_yaw[b].  A cursor that does not match the carried scan (a caller moved it, another kernel
 // advanced it) is caught at launch and the scan is rebuilt from row 0.  No yaw bytes are read or written at all.
-template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN>
+template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN, bool ADMA = false>
 __global__ void __launch_bounds__((LOG_STATE || LOG_CMD || AABB) ? 64 * CW + 128 : 64 * CW)       // compute [+ placeholder] + store
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
@@ -194,8 +238,19 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         const bool mine = col0 + lane < B;
         int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
         if (AABB_HERE) settle(coll);               // landed before the tick loop (see above)
+#ifdef UAVAC_DIAG_STAMPS
+        long long dg_wait = 0, dg_issue = 0;
+        const long long dg_t0 = DIAG_NOW();
+#endif
         for (int k = 0; k < K; ++k) {
+#ifdef UAVAC_DIAG_STAMPS
+            const long long dg_a = DIAG_NOW();
+            lds_barrier();
+            const long long dg_b = DIAG_NOW();
+            dg_wait += dg_b - dg_a;
+#else
             lds_barrier();                                             // slab k&1 is complete (stores of earlier ticks stay in flight)
+#endif
             const double *src = slab + (size_t)((kk + k) & 1) * NR * NU + lane;
             // one log (13 or 12 rows) at a time: every LDS read first, then every store, so that neither the
             // LDS latency nor the store path's acceptance time is paid per element
@@ -203,7 +258,12 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 double v[13];
 #pragma unroll
                 for (int r = 0; r < 13; ++r) v[r] = src[r * NU];
+#ifdef UAVAC_DIAG_LOG_WRAP      // DIAGNOSTIC builds only (tools/log_wrap_probe.sh): every tick overwrites the first UAVAC_DIAG_LOG_WRAP log slots,
+                                // so the log stream stays in L2 instead of reaching HBM -- same instructions, same store path in the CU
+                double *dst = state_log + (size_t)(k % UAVAC_DIAG_LOG_WRAP) * 13 * sP + col0;
+#else
                 double *dst = state_log + (size_t)k * 13 * sP + col0;               // wave-uniform: lives in SGPRs
+#endif
 #pragma unroll
                 for (int r = 0; r < 13; ++r) {
                     if (full || mine) store_uniform_base(dst + r * sP, lane_bytes, v[r]);      // 512-B coalesced wave store
@@ -249,7 +309,16 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 for (int r = 0; r < UAVAC_CMD_COLS; ++r)
                     if (full || mine) store_uniform_base(dst + r * sP, lane_bytes, v[r]);
             }
+#ifdef UAVAC_DIAG_STAMPS
+            dg_issue += DIAG_NOW() - dg_b;
+#endif
         }
+#ifdef UAVAC_DIAG_STAMPS
+        if (lane == 0 && blockIdx.x < 8192) {
+            g_uavac_diag[blockIdx.x * 8 + 3] = dg_issue;
+            g_uavac_diag[blockIdx.x * 8 + 4] = DIAG_NOW() - dg_t0;
+        }
+#endif
         if (AABB_HERE && mine) istate[2 * sB + col0 + lane] = coll;
       }
         return;
@@ -319,8 +388,12 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     if (!POLY && nrows > 0) row_issue(nxt, rows + (size_t)min(max(idx, 0), nrows - 1) * UAVAC_TRAJ_COLS);
 
     // POLY: segment / row-in-segment of the cursor, the segment's coefficients and the next 16 yaws, in LDS
-    double *cf = slab + (size_t)2 * NR * NU + (size_t)(tid >> 6) * poly_tile_doubles(YAWSCAN) + (tid & 63);      // cf[j * 64]
-    double *yw = cf + 24 * 64;                                                                          // yw[j * 64]
+    // this wave's coefficient tile: [24][64] doubles, or -- filled by LDS-DMA -- [12][64][2] (minsnap_eval.h, STRIDE 0)
+    constexpr int CST = ADMA ? 0 : 64;
+    double *tile = slab + (size_t)2 * NR * NU + (size_t)(tid >> 6) * poly_tile_doubles(YAWSCAN);
+    double *cf = tile + (ADMA ? 2 : 1) * (tid & 63);                                                    // this lane's first coefficient
+    double *yw = tile + 24 * 64 + (tid & 63);                                                           // yw[j * 64]
+    const unsigned tile_lds = ADMA ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)tile) : 0u;   // LDS byte address (low half of the generic pointer)
     // segments of this lane's mission: P.m of them at bb * P.m, or -- ragged batch -- seg_offsets[bb + 1] - seg_offsets[bb]
     // of them at seg_offsets[bb] (clamped to 1 .. P.m, the batch's maximum)
     int pm = P.m;
@@ -334,10 +407,11 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     const double *mission_coeffs = POLY ? P.coeffs + seg0 * 24 : nullptr;
     const double *yaws = (POLY && !YAWSCAN) ? P.yaw + off : nullptr;
     int seg = 0, rin = 0, srows = 0, ybase = 0;
-    auto load_coeffs = [&](int s_) {
+    int srows_nx = 0;                              // rows of segment seg + 1 (in flight from the moment seg is entered: plan_loads_wait)
+    auto load_coeffs = [&](int s_) {               // through registers, on the spot: launch start and the scan's rebuild only
         const double *src = mission_coeffs + 24 * s_;
 #pragma unroll
-        for (int j = 0; j < 24; ++j) cf[j * 64] = src[j];
+        for (int j = 0; j < 24; ++j) cf[minsnap_coeff_index<CST>(j)] = src[j];
     };
     auto load_yaws = [&](int base_) {
 #pragma unroll
@@ -363,7 +437,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 for (int row = 0; row < idx; ++row) {
                     while (r_ >= n_ && s_ + 1 < pm) { r_ -= n_; ++s_; n_ = seg_rows[s_]; load_coeffs(s_); }
                     double x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_;
-                    minsnap_eval_row<64>(cf, (double)r_ * plan_dt, x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_);
+                    minsnap_eval_row<CST>(cf, (double)r_ * plan_dt, x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_);
                     if (uavac_yaw::has_heading(vx_, vy_)) {
                         const double a_ = atan2(vy_, vx_);
                         if (yhas) ysum = ysum + uavac_yaw::unwrap_correction(a_ - yprev);
@@ -378,11 +452,13 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         srows = seg_rows[0];
         while (seg + 1 < pm && rin >= srows) { rin -= srows; ++seg; srows = seg_rows[seg]; }
         load_coeffs(seg);
+        if (ADMA) srows_nx = seg_rows[min(seg + 1, pm - 1)];
         if (!YAWSCAN) {
             ybase = idx;
             load_yaws(ybase);
         }
     }
+    if (POLY && ADMA) settle(srows_nx);
 
     // 1/|q|^2 of the caller-supplied attitude; the free-body step leaves q unit, so 1 from then on
     // (a state this kernel wrote earlier is unit to rounding: take exactly 1 so that splitting a rollout over
@@ -390,12 +466,21 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     const double qn2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
     double inv_n2 = (fabs(qn2 - 1.0) < 1.0e-12) ? 1.0 : 1.0 / qn2;
 
+#ifdef UAVAC_DIAG_STAMPS
+    long long dgc_wait = 0, dgc_seg[4] = {0, 0, 0, 0}, dgc_out[4] = {0, 0, 0, 0};
+    const long long dgc_t0 = DIAG_NOW();
+    long long dgc_last = dgc_t0;
+#endif
     for (int k = 0; k < K; ++k) {
         if (phase == 0 && nrows > 0) {
             // ------------------------------------------------------------- outer loop (main.py:47-61)
             double tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az, tg_yaw;
+#ifdef UAVAC_DIAG_STAMPS
+            const long long dg_o0 = DIAG_NOW();
+#endif
             if (POLY) {
-                minsnap_eval_row<64>(cf, (double)rin * plan_dt, tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az);
+                if (ADMA) plan_loads_wait(srows_nx);            // coefficients (and row count) asked for an outer tick ago have landed
+                minsnap_eval_row<CST>(cf, (double)rin * plan_dt, tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az);
                 if (YAWSCAN) {
                     // this row's yaw from the carried scan (minimum_snap.py:126-136); committed below only if the cursor moves on
                     const bool yvalid = uavac_yaw::has_heading(tg_vx, tg_vy);
@@ -417,7 +502,18 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 tg_yaw = row_col(nxt, 9);
             }
 
+#ifdef UAVAC_DIAG_STAMPS
+            asm volatile("" : "+v"(tg_x), "+v"(tg_yaw), "+v"(tg_az));
+            const long long dg_o1 = DIAG_NOW();
+            dgc_out[0] += dg_o1 - dg_o0;                                 // the target row: evaluation + yaw (POLY) or wait for the prefetched row
+#endif
             const VehK O = outer_constants();
+#ifdef UAVAC_DIAG_STAMPS
+            double o_probe = O.g + O.kp_yaw + O.kd_z;                   // the scalar loads have landed
+            asm volatile("" : "+v"(o_probe));
+            const long long dg_o2 = DIAG_NOW();
+            dgc_out[1] += dg_o2 - dg_o1;                                 // constants of the outer loop from the kernarg segment (scalar loads)
+#endif
             const Rot R = quat_to_rot(q0, q1, q2, q3);                 // shared by altitude and attitude
             thrust_cmd = altitude(O, tg_z, tg_vz, tg_az, pz, vz, R.r22, integ);
             double bxc, byc;
@@ -426,14 +522,26 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             double psi, cth, sphi, cphi;
             euler_trig(q0, q1, q2, q3, psi, cth, sphi, cphi);
             rc = yaw_rate(O, tg_yaw, psi, cth, sphi, cphi, qc);
+#ifdef UAVAC_DIAG_STAMPS
+            asm volatile("" : "+v"(rc), "+v"(pc), "+v"(qc), "+v"(thrust_cmd));
+            const long long dg_o3 = DIAG_NOW();
+            dgc_out[2] += dg_o3 - dg_o2;                                 // altitude, lateral, attitude, yaw rate
+#endif
             // next row (main.py:61), consumed F ticks from now; issued last so that nothing in this block
             // still reads the registers it overwrites
             if (POLY) {
                 if (idx + 1 < nrows) {                    // main.py:61: the cursor stops on the last row
                     ++idx;
                     if (++rin >= srows) {                 // next segment (skipping empty ones, like the sampler's segment_of)
-                        while (rin >= srows && seg + 1 < pm) { rin -= srows; ++seg; srows = seg_rows[seg]; }
-                        load_coeffs(seg);
+                        if (!ADMA) {                      // full chip: through registers, on the spot (see the launcher)
+                            while (rin >= srows && seg + 1 < pm) { rin -= srows; ++seg; srows = seg_rows[seg]; }
+                            load_coeffs(seg);
+                        } else if (seg + 1 < pm) {
+                            rin -= srows; ++seg; srows = srows_nx;             // (its row count came with the segment before)
+                            while (rin >= srows && seg + 1 < pm) { rin -= srows; ++seg; srows = seg_rows[seg]; }    // empty segments: rare, on the spot
+                            coeffs_dma(mission_coeffs + 24 * seg, tile_lds);   // lands in this lane's column while the inner ticks run
+                            seg_rows_issue(srows_nx, seg_rows + min(seg + 1, pm - 1));
+                        }
                     }
                     if (!YAWSCAN && idx - ybase == 16) { ybase = idx; load_yaws(ybase); }
                 }
@@ -441,16 +549,34 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 idx = min(idx + 1, nrows - 1);
                 row_issue(nxt, rows + (size_t)idx * UAVAC_TRAJ_COLS);
             }
+#ifdef UAVAC_DIAG_STAMPS
+#if UAVAC_DIAG_STAMPS > 1     // 2: also wait for what the block issued (exposes the latency of the loads it started)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+            dgc_out[3] += DIAG_NOW() - dg_o3;                            // cursor advance; a lane that enters a new segment loads its coefficients
+#endif
         }
 
         // ----------------------------------------------------------------- inner loop, every tick
+#ifdef UAVAC_DIAG_STAMPS
+        const long long dg_s0 = DIAG_NOW();
+        dgc_seg[0] += dg_s0 - dgc_last;               // what lies between two ticks: loop control + (every F-th tick) the outer loop
+#endif
         double Mx, My, Mz, f[4];
         body_rate(L, pc, qc, rc, wp, wq, wr, Mx, My, Mz);
         allocate(L, thrust_cmd, Mx, My, Mz, f);
         motors(L, f, om, omc);
+#ifdef UAVAC_DIAG_STAMPS
+        const long long dg_s1 = DIAG_NOW();
+        dgc_seg[1] += dg_s1 - dg_s0;                  // body rates, allocation, motors
+#endif
         // late hand-over: slab k-1 goes to the store wave HERE, a third of a tick after it was written -- the barrier's wait for
         // this wave's LDS writes then finds nothing outstanding (the launcher says when that pays)
+#ifdef UAVAC_DIAG_STAMPS
+        if (LOGGING && late_handover && k > 0) { const long long a_ = DIAG_NOW(); lds_barrier(); dgc_wait += DIAG_NOW() - a_; }
+#else
         if (LOGGING && late_handover && k > 0) lds_barrier();
+#endif
 
         double *my = LOGGING ? slab + (size_t)((kk + k) & 1) * NR * NU + tid : nullptr;
         if (LOG_CMD) {
@@ -477,19 +603,38 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             }
         }
 
+#ifdef UAVAC_DIAG_STAMPS
+        const long long dg_s2 = DIAG_NOW();
+        dgc_seg[2] += dg_s2 - dg_s1;                  // (late barrier,) free-body step
+#endif
         if (LOG_STATE) {
             my[0] = px; my[1 * NU] = py; my[2 * NU] = pz;
             my[3 * NU] = q0; my[4 * NU] = q1; my[5 * NU] = q2; my[6 * NU] = q3;
             my[7 * NU] = vx; my[8 * NU] = vy; my[9 * NU] = vz;
             my[10 * NU] = wp; my[11 * NU] = wq; my[12 * NU] = wr;
         }
+#ifdef UAVAC_DIAG_STAMPS
+        { const long long a_ = DIAG_NOW(); dgc_seg[3] += a_ - dg_s2;  /* the 13 slab writes */
+          if (LOGGING && !late_handover) { lds_barrier(); dgc_wait += DIAG_NOW() - a_; }
+          dgc_last = DIAG_NOW(); }
+#else
         if (LOGGING && !late_handover) lds_barrier();        // hand slab (kk+k)&1 to the store wave; it was drained two ticks ago
+#endif
         ++inner;
         phase = (phase + 1 == V.F) ? 0 : phase + 1;
     }
     if (LOGGING && late_handover && K > 0) lds_barrier();      // the last slab
+#ifdef UAVAC_DIAG_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_uavac_diag[blockIdx.x * 8 + 0] = DIAG_NOW() - dgc_t0; g_uavac_diag[blockIdx.x * 8 + 1] = dgc_wait;
+        g_uavac_diag[blockIdx.x * 8 + 5] = dgc_seg[0]; g_uavac_diag[blockIdx.x * 8 + 6] = dgc_seg[1]; g_uavac_diag[blockIdx.x * 8 + 7] = dgc_seg[2];
+        g_uavac_diag[blockIdx.x * 8 + 2] = dgc_seg[3];      /* (the store wave's barrier time moves out: slot 2 is the slab writes now) */
+        for (int q_ = 0; q_ < 4; ++q_) g_uavac_diag2[blockIdx.x * 4 + q_] = dgc_out[q_];
+    }
+#endif
 
     if (!POLY && nrows > 0) row_wait(nxt);          // nothing may stay in flight into these registers
+    if (POLY && ADMA) plan_loads_wait(srows_nx);    // ... nor into this wave's coefficient tile (the next pass, or nobody, owns it)
     if (live) {
     state[0 * sB + b] = px; state[1 * sB + b] = py; state[2 * sB + b] = pz;
     state[3 * sB + b] = q0; state[4 * sB + b] = q1; state[5 * sB + b] = q2; state[6 * sB + b] = q3;
@@ -547,7 +692,7 @@ __global__ void __launch_bounds__(256) rollout_align_kernel() {}
 // per 1 000 ticks against 1.33 ms: the per-tick barrier then couples eight waves; round 3 measured two + two waves per 128 UAVs
 // slower at every batch size as well, profiles/r03_rollout_shapes_wide_workgroup.jsonl.  The kernel keeps its CW / SW
 // parameters; only <1, 1> is instantiated.)
-template <bool LS, bool LC, bool AB, bool POLY, bool GR, bool YS>
+template <bool LS, bool LC, bool AB, bool POLY, bool GR, bool YS, bool ADMA = false>
 void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                   int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                   const PlanRef &P) {
@@ -566,7 +711,7 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     }
     const int threads = NU + (LOGGING ? 64 * (1 + n_idle) : 0);
     const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0));
-    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS>;
+    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS, ADMA>;
     if (lds + (size_t)ctx->lds_pad > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)ctx->lds_pad));
     // With a second wave per workgroup the launch holds at most one workgroup per SIMD; a batch with more 64-UAV tiles than
@@ -585,14 +730,19 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     const int late = ctx->late_handover >= 0 ? ctx->late_handover
                                              : ((cols > 20 * ctx->n_simds && cols < 40 * ctx->n_simds) ? 0 : 1);
     const size_t pitch = (LS || LC) ? (ctx->log_pitch > 0 ? (size_t)ctx->log_pitch : (size_t)B) : (size_t)B;
+    // Plan-fed: how a lane's next segment reaches the coefficient tile.  By LDS-DMA, asynchronously (see coeffs_dma), while the
+    // chip is not full -- per 1 000 logged ticks against the reload through registers, same process, same buffers
+    // (tools/rollout_ab.py, m = 12): 0.834 / 0.852 ms at 16 384 UAVs, 0.891 / 0.984 at 32 768, 0.997 / 1.055 at 49 152 -- and
+    // through registers on the full chip, where a launch is bound by its log stream and the twelve DMA instructions per
+    // segment change are only in the way: 1.27 / 1.25 ms at 65 536.  Same bits either way.
     if (LOGGING && ctx->rollout_align)
         hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(threads), 0, ctx->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds + (size_t)ctx->lds_pad, ctx->stream, V, traj, row_offsets, state, istate,
                        B, K, state_log, cmd_log, aabbs, n_obs, n_tiles, pitch, P, late, n_idle);
     auto tf = [](bool v) { return v ? "true" : "false"; };
     char name[176];
-    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
-             tf(GR), tf(YS));
+    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s%s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
+             tf(GR), tf(YS), ADMA ? ", true" : "");
     ctx->last_rollout = name;
     // vector registers of that kernel as the loaded code object has them (once per variant): above 256 a SIMD holds ONE
     // wave of it and the launch runs at 0.65x -- a toolchain that crosses the line shows up here and in bench.py's line
@@ -609,12 +759,31 @@ void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int
                     int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                     const PlanRef *plan) {
 #define UAVAC_SHAPE_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs
+    // Plan-fed: how a lane's next segment reaches the coefficient tile.  By LDS-DMA, asynchronously (see coeffs_dma), while the
+    // chip is not full -- per 1 000 logged ticks against the reload through registers, same process, same buffers
+    // (tools/rollout_ab.py, m = 12): 0.834 / 0.852 ms at 16 384 UAVs, 0.891 / 0.984 at 32 768, 0.997 / 1.055 at 49 152 -- and
+    // through registers on the full chip, where a launch is bound by its log stream and the twelve DMA instructions per
+    // segment change are only in the way: 1.27 / 1.25 ms at 65 536.  Same bits either way.  (A template parameter, not a
+    // branch: with both forms in one kernel the plan-fed variants need 257-260 vector registers.)
+    constexpr bool LOGGING = LS || LC || AB;
+    const int tiles = (B + 63) / 64, in_flight = (LOGGING && tiles > ctx->n_simds) ? ctx->n_simds : tiles;
+    const bool dma = plan && (ctx->coeff_dma >= 0 ? ctx->coeff_dma != 0 : in_flight * 64 < 60 * ctx->n_simds);
     if (plan && !plan->yaw) {                       // the rollout scans the yaw itself
-        if (V.ground) launch_shape<LS, LC, AB, true, true, true>(UAVAC_SHAPE_ARGS, *plan);
-        else launch_shape<LS, LC, AB, true, false, true>(UAVAC_SHAPE_ARGS, *plan);
+        if (dma) {
+            if (V.ground) launch_shape<LS, LC, AB, true, true, true, true>(UAVAC_SHAPE_ARGS, *plan);
+            else launch_shape<LS, LC, AB, true, false, true, true>(UAVAC_SHAPE_ARGS, *plan);
+        } else {
+            if (V.ground) launch_shape<LS, LC, AB, true, true, true>(UAVAC_SHAPE_ARGS, *plan);
+            else launch_shape<LS, LC, AB, true, false, true>(UAVAC_SHAPE_ARGS, *plan);
+        }
     } else if (plan) {
-        if (V.ground) launch_shape<LS, LC, AB, true, true, false>(UAVAC_SHAPE_ARGS, *plan);
-        else launch_shape<LS, LC, AB, true, false, false>(UAVAC_SHAPE_ARGS, *plan);
+        if (dma) {
+            if (V.ground) launch_shape<LS, LC, AB, true, true, false, true>(UAVAC_SHAPE_ARGS, *plan);
+            else launch_shape<LS, LC, AB, true, false, false, true>(UAVAC_SHAPE_ARGS, *plan);
+        } else {
+            if (V.ground) launch_shape<LS, LC, AB, true, true, false>(UAVAC_SHAPE_ARGS, *plan);
+            else launch_shape<LS, LC, AB, true, false, false>(UAVAC_SHAPE_ARGS, *plan);
+        }
     } else {
         if (V.ground) launch_shape<LS, LC, AB, false, true, false>(UAVAC_SHAPE_ARGS, PlanRef{});
         else launch_shape<LS, LC, AB, false, false, false>(UAVAC_SHAPE_ARGS, PlanRef{});

@@ -6,16 +6,23 @@
 // c[(3 i + axis) * STRIDE] = coefficient of t^i (STRIDE 1: the mission's (8,3) block; 64: a [24][64] LDS tile).
 #pragma once
 
+// STRIDE 0: the PAIRED tile of the plan-fed rollout, [12][64][2] doubles -- coefficient k of lane l at ((k >> 1) * 64 + l) * 2 +
+// (k & 1), c pointing at the lane's first pair: the layout in which twelve 16-byte LDS-DMA loads per lane deposit a segment's
+// 24 coefficients (control_rollout.hip).  Same coefficients, same operations, same bits.
+template <int STRIDE>
+__device__ __forceinline__ constexpr int minsnap_coeff_index(int k) { return STRIDE == 0 ? (k >> 1) * 128 + (k & 1) : k * STRIDE; }
+
 template <int STRIDE>
 __device__ __forceinline__ void minsnap_eval_row(const double *c, double t, double &px, double &py, double &pz,
                                                  double &vx, double &vy, double &vz, double &ax, double &ay, double &az) {
     double d1x = 0, d1y = 0, d1z = 0, d2x = 0, d2y = 0, d2z = 0;
-    px = c[21 * STRIDE]; py = c[22 * STRIDE]; pz = c[23 * STRIDE];
+    px = c[minsnap_coeff_index<STRIDE>(21)]; py = c[minsnap_coeff_index<STRIDE>(22)]; pz = c[minsnap_coeff_index<STRIDE>(23)];
 #pragma unroll
     for (int i = 6; i >= 0; --i) {
         d2x = fma(d2x, t, d1x); d2y = fma(d2y, t, d1y); d2z = fma(d2z, t, d1z);
         d1x = fma(d1x, t, px);  d1y = fma(d1y, t, py);  d1z = fma(d1z, t, pz);
-        px = fma(px, t, c[(3 * i) * STRIDE]); py = fma(py, t, c[(3 * i + 1) * STRIDE]); pz = fma(pz, t, c[(3 * i + 2) * STRIDE]);
+        px = fma(px, t, c[minsnap_coeff_index<STRIDE>(3 * i)]); py = fma(py, t, c[minsnap_coeff_index<STRIDE>(3 * i + 1)]);
+        pz = fma(pz, t, c[minsnap_coeff_index<STRIDE>(3 * i + 2)]);
     }
     vx = d1x; vy = d1y; vz = d1z;
     ax = 2.0 * d2x; ay = 2.0 * d2y; az = 2.0 * d2z;

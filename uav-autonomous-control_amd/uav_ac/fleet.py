@@ -874,11 +874,81 @@ class Fleet:
 
 
 # ---------------------------------------------------------------------- multi-GPU
-def shard_bounds(B: int, rank: int, world: int):
-    """Contiguous mission-index block of this rank: no data-path collective needed."""
-    base, rem = divmod(B, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+def shard_sizes(B: int, world: int, root_share: float = None, root: int = 0):
+    """Missions per rank: contiguous blocks in rank order.  Equal blocks (sizes differ by at most one) unless
+    `root_share` is given: then rank `root` -- the rank the trajectories are gathered to -- takes round(root_share * B)
+    missions (at least 1 when B >= world) and the other ranks share the rest equally.  The root of the final gather has
+    extra work (it re-samples or receives everybody's rows while it flies), so its block is made smaller:
+    `balanced_root_share` says by how much."""
+    B, world = int(B), int(world)
+    if world < 1 or B < 0 or not (0 <= root < world):
+        raise ValueError("need world >= 1, B >= 0, 0 <= root < world")
+    if root_share is None or world == 1:
+        base, rem = divmod(B, world)
+        return [base + (1 if r < rem else 0) for r in range(world)]
+    if not (0.0 <= root_share <= 1.0):
+        raise ValueError("root_share is a fraction of the batch")
+    n_root = int(round(root_share * B))
+    n_root = max(min(n_root, B), 1 if B >= world else 0)
+    n_root = min(n_root, B - (world - 1) if B >= world else n_root)     # every peer keeps at least one mission
+    base, rem = divmod(B - n_root, world - 1)
+    peers = [base + (1 if i < rem else 0) for i in range(world - 1)]
+    return peers[:root] + [n_root] + peers[root:]
+
+
+def shard_bounds(B: int, rank: int, world: int, root_share: float = None, root: int = 0):
+    """Contiguous mission-index block [lo, hi) of this rank: no data-path collective needed.  Sizes: `shard_sizes`."""
+    sizes = shard_sizes(B, world, root_share, root)
+    lo = sum(sizes[:rank])
+    return lo, lo + sizes[rank]
+
+
+# One MI355X, measured (profiles/NOTES.md A1, r03_config_sweep): time of one logged tick by batch size, us
+_TICK_US = ((4096, 0.76), (16384, 0.766), (24576, 0.842), (32768, 0.871), (49152, 1.0), (65536, 1.25))
+
+
+def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_segment: float = 112.9,
+                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 5.8e12) -> float:
+    """The share of a B-mission job the gather's root should take so that it finishes with its peers (BASELINE configs[3]).
+
+    A PROJECTION from one-GPU measurements on MI355X, not a measurement of N GPUs: a peer with n missions plans them
+    (sampler-bound, 88 B per row at ~5.3 TB/s) and flies `ticks` logged ticks (`_TICK_US`, linear above 65 536 UAVs); the
+    root does the same for its own block and, beside it, receives the peers' plans and re-samples their rows (plan gather)
+    or receives the rows themselves -- either way its HBM takes the peers' rows on top of its own log (104 B per UAV
+    tick), so its time is the larger of its flight and of (log + all rows) / the HBM write rate.  Bisection on the share."""
+    if world <= 1:
+        return 1.0
+    row_bytes = 88.0 * rows_per_segment * segments                       # per mission
+
+    def tick_us(n):
+        if n <= _TICK_US[0][0]:
+            return _TICK_US[0][1]
+        for (n0, t0), (n1, t1) in zip(_TICK_US, _TICK_US[1:]):
+            if n <= n1:
+                return t0 + (t1 - t0) * (n - n0) / (n1 - n0)
+        return _TICK_US[-1][1] * n / _TICK_US[-1][0]
+
+    def own(n):                                                          # plan + flight of n missions, seconds
+        return n * row_bytes / 5.3e12 + ticks * tick_us(n) * 1e-6
+
+    def root_time(s):
+        n = s * B
+        stream = (n * ticks * 104.0 + B * row_bytes) / hbm_write_bytes_per_s
+        return max(own(n), stream) if plan_gather else own(n) + (B - n) * row_bytes / (7 * 153e9 * min(1.0, (world - 1) / 7.0))
+
+    def peer_time(s):
+        return own((1.0 - s) * B / (world - 1))
+
+    lo, hi = 0.0, 1.0 / world
+    if root_time(hi) <= peer_time(hi):
+        return hi                                                        # equal blocks already balance
+    for _ in range(50):
+        mid = 0.5 * (lo + hi)
+        if root_time(mid) > peer_time(mid):
+            hi = mid
+        else:
+            lo = mid
+    return 0.5 * (lo + hi)
 
 
 def gather_layout(counts, dst: int):
