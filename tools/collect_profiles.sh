@@ -10,10 +10,10 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 bash tools/box_mode.sh 2>&1 | grep -E "Unique|sampler" | head -2 > "$OUT/box.txt"
 # 1. kernel trace + stats of the bench command (HIP-event average in the JSON line must agree with the trace average)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config4 > "$OUT/${TAG}_bench_profiled.json" 2> "$OUT/trace.err"
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config4 > "$OUT/${TAG}_bench_profiled.json" 2> "$OUT/trace.err"
 python3 tools/summarize_trace.py "$(ls $OUT/trace/*kernel_trace.csv | head -1)" "$OUT/${TAG}_bench" > "$OUT/per_dispatch_summary.txt"
 # 2. PMC traffic (three passes) -> hbm_traffic.json + pmc summary
-python3 tools/pmc_traffic.py > "$OUT/pmc_traffic.log" 2>&1
+timeout -s KILL 900 python3 tools/pmc_traffic.py > "$OUT/pmc_traffic.log" 2>&1
 cp gpurun_out/hbm_traffic.json "$OUT/hbm_traffic.json"; cp gpurun_out/${TAG}_pmc_summary.csv "$OUT/${TAG}_pmc_summary.csv"
 cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json      # so that the bench of step 3 quotes it
 # 3. the plain bench line (what the driver runs)
@@ -22,7 +22,7 @@ python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 python3 tools/config_sweep.py > "$OUT/${TAG}_config_sweep.jsonl" 2>/dev/null
 # 5. small batch: where the cycles go
 python3 tools/small_batch_profile.py 2>/dev/null | tail -1 > "$OUT/${TAG}_small_batch.json"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pmc_small" -o pmc -- python3 tools/small_batch_profile.py > /dev/null 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pmc_small" -o pmc -- python3 tools/small_batch_profile.py > /dev/null 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, collections, json, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -39,8 +39,11 @@ python3 tools/single_uav_loop.py 2>/dev/null | tail -4 > "$OUT/${TAG}_single_uav
 python3 tools/host_path_rate.py 2>/dev/null | tail -2 > "$OUT/${TAG}_host_path_rate.txt"
 python3 tools/first_launch_bisect.py 2>/dev/null | grep "^|" > "$OUT/${TAG}_first_launch_bisect.md"
 # 7. round 3: effective clock of the rollout by batch size, obstacle-loop rate
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_rclock" -o pmc -- python3 tools/rollout_clock.py > /dev/null 2>&1
+timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_rclock" -o pmc -- python3 tools/rollout_clock.py > /dev/null 2>&1
 python3 tools/rollout_clock.py --report "$OUT/pmc_rclock" > "$OUT/${TAG}_rollout_clock.jsonl" 2>/dev/null
 python3 tools/replan_rate.py 4096 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_replan_rate.txt"
+# 8. round 4: the two sampler kernels on six row buffers side by side; plan-fed against row-fed rollout by batch size
+python3 tools/sampler_stream_ab.py 6 65536 12 1x1,4x1,2x1,8x1,4x2 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_sampler_stream_ab.jsonl"
+python3 tools/plan_vs_rows.py 2>/dev/null | grep "B=" > "$OUT/${TAG}_plan_vs_rows.txt"
 rm -rf "$OUT/trace/"*results.db "$OUT/pmc_small" "$OUT/pmc_rclock"
 ls -la "$OUT"

@@ -6,7 +6,7 @@ import torch
 from bench import missions
 from uav_ac.fleet import Engine
 eng = Engine("cuda:0")
-for B in (4096, 16384, 32768, 49152, 65536, 131072):
+for B in (4096, 8192, 16384, 20480, 24576, 28672, 32768, 36864, 40960, 49152, 65536, 131072):
     plan = eng.plan(missions(B, 12, 0, B), 3.0, 0.01)
     log = torch.empty((1000, 13, B), dtype=torch.float64, device="cuda:0")
     out = {True: [], False: []}

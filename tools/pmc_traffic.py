@@ -39,7 +39,7 @@ def collect(counter):
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
            "python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-config4",
            "--no-extras"]
-    subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL)
+    subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, timeout=280)
     path = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     per = {}
     with open(path) as fh:
@@ -51,8 +51,12 @@ def collect(counter):
                     # the bench's own launches only (the 8-mission oracle check uses tiny grids)
                     big = int(r["Grid_Size"]) >= B_PER_GPU
                     if big:
-                        name = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "")
-                        per.setdefault((key, name.split("(")[0]), []).append(float(r["Counter_Value"]))
+                        name = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0]
+                        # the library names a rollout variant by its first eight template arguments and appends the ninth
+                        # (coefficients by LDS-DMA) only when it is true: the same here
+                        if key == "control_rollout" and name.endswith(", false>") and name.count(",") == 8:
+                            name = name[:-len(", false>")] + ">"
+                        per.setdefault((key, name), []).append(float(r["Counter_Value"]))
     return per
 
 

@@ -31,6 +31,14 @@
 #include "minsnap_eval.h"
 #include "minsnap_yaw.h"
 
+#ifdef UAVAC_DIAG_STAMPS      // DIAGNOSTIC builds only (tools/sampler_stamps_probe.py): where an item's cycles go, per wave
+__device__ long long g_uavac_sdiag[65536 * 4];      // per workgroup: cycles evaluating / waiting / writing out, items (summed over its waves)
+#define SDIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())
+extern "C" int uavac_sampler_diag_read(long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uavac_sdiag), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace {
 
 constexpr int kChunkRows = 64;
@@ -81,7 +89,7 @@ __device__ __forceinline__ int padded_pre(int m) { return (m + 2 + 1) & ~1; }
 // HITS / DERIVS / RAGGED as in minsnap_sample.hip.  G = missions per workgroup; phase = rows by which the 64-row grid is
 // shifted so that chunk starts are 128-byte aligned in `traj` (0 .. 63, from the buffer's address).
 template <int W, bool HITS, bool DERIVS, bool RAGGED>
-__global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_sample_stream_kernel(
+__global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_sample_stream_kernel(
     const double *__restrict__ coeffs, const int32_t *__restrict__ seg_rows, const int64_t *__restrict__ row_offsets, int B,
     int m, double dt, double *__restrict__ traj, const double *__restrict__ aabb, int32_t *__restrict__ hit,
     double *__restrict__ yaw_dense, double *__restrict__ jerk, double *__restrict__ snap, int64_t capacity_rows,
@@ -147,6 +155,12 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
 
     // ---- items in address order; this wave takes those congruent to w modulo W.  Everything that steers the loops is
     // wave-uniform and kept in scalar registers (readfirstlane: values read from LDS are not uniform to the compiler).
+#ifdef UAVAC_DIAG_STAMPS
+    long long sdg[4] = {0, 0, 0, 0};
+    __shared__ long long sdg_lds[4];
+    if (tid < 4) sdg_lds[tid] = 0;
+    __syncthreads();
+#endif
     int item0 = 0;                                   // workgroup-local index of mission j's first item
     for (int j = 0; j < Gn; ++j) {
         const long long Rj = uniform64(rowoff[j]), Rj1 = uniform64(rowoff[j + 1]);
@@ -163,6 +177,9 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
         const int endv = (lane < mb) ? prej[lane + 1] : 0x7fffffff;       // lane s: first row past segment s
         int i = item0 + ((w - item0) % W + W) % W;                        // first item >= item0 congruent to w
         for (; i < item0 + nitems; i += W) {
+#ifdef UAVAC_DIAG_STAMPS
+            const long long sd0 = SDIAG_NOW();
+#endif
             const long long g0 = ((kfirst + (i - item0)) << 6) - phase;   // row (of the batch) in lane 0; may lie before the buffer
             const int rel0 = (int)(g0 - Rj);                              // the same, counted from the mission's first row
             const int r = rel0 + lane;
@@ -213,6 +230,10 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
             bool c_has = false;
             double c_ang = 0.0, c_sum = 0.0, c_first = 0.0;
             // (the hand-over is the one serial piece of a workgroup: it runs ahead of the other waves of its SIMD)
+#ifdef UAVAC_DIAG_STAMPS
+            asm volatile("" : "+v"(corr));
+            const long long sd1 = SDIAG_NOW();
+#endif
             __builtin_amdgcn_s_setprio(2);
             if (i > 0) {
                 const unsigned src = lds_address(&mail[w == 0 ? W - 1 : w - 1]);
@@ -231,6 +252,9 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
                     c_ang = uniform_double(ca); c_sum = uniform_double(cs); c_first = uniform_double(cf);
                 }
             }
+#ifdef UAVAC_DIAG_STAMPS
+            const long long sd2 = SDIAG_NOW();
+#endif
             // np.unwrap's step from the last heading before this item to its first one, then np.cumsum's order, left to right
             const double cb = (mask != 0ull && c_has) ? unwrap_correction(first_ang - c_ang) : 0.0;
             if (lane == first_lane && valid) corr = cb;                     // (0 unless c_has: that lane has no predecessor)
@@ -276,10 +300,21 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
                 *reinterpret_cast<double2 *>(dst + 2 * p) = v;
             }
             lds_wave_fence();                     // the staged chunk is in registers / on its way; its stores stay in flight
+#ifdef UAVAC_DIAG_STAMPS
+            {
+                const long long sd3 = SDIAG_NOW();
+                sdg[0] += sd1 - sd0; sdg[1] += sd2 - sd1; sdg[2] += sd3 - sd2; sdg[3] += 1;       // evaluation + staging + headings / wait for the carry / hand-over + yaw + write-out
+            }
+#endif
         }
         item0 += nitems;
     }
 
+#ifdef UAVAC_DIAG_STAMPS
+    if (lane == 0) for (int q_ = 0; q_ < 4; ++q_) atomicAdd((unsigned long long *)&sdg_lds[q_], (unsigned long long)sdg[q_]);
+    __syncthreads();
+    if (tid < 4 && blockIdx.x < 65536) g_uavac_sdiag[blockIdx.x * 4 + tid] = sdg_lds[tid];
+#endif
     // ---- leading rows that were written before their mission's first heading was known
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
