@@ -498,19 +498,25 @@ def test_plan_fed_rollout_equals_row_fed_rollout(eng):
         a, b, d = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False), eng.fleet(plan, from_plan=True, yaw_from="column")
         assert a.from_plan and not b.from_plan and d.from_plan
         la, ca = a.rollout(K, state_log=True, cmd_log=True)
-        # plan-fed, free flight, yaw scan; the chip is far from full: the next segment's coefficients arrive by LDS-DMA (9th argument)
-        assert eng.ctx.last_rollout_kernel().endswith("true, false, true, true>")
+        # plan-fed, free flight, yaw scan; there is a second wave: IT owns the cursor and evaluates the target rows (9th argument: 2)
+        assert eng.ctx.last_rollout_kernel().endswith("true, false, true, 2>")
         lb, cb = b.rollout(K, state_log=True, cmd_log=True)
         ld, cd = d.rollout(K, state_log=True, cmd_log=True)
-        assert eng.ctx.last_rollout_kernel().endswith("true, false, false, true>")   # plan-fed, yaw from the dense column
-        # the same through registers on the spot (what a full chip uses): the same bits
-        eng.ctx.set_option("coeff_dma", 0)
+        assert eng.ctx.last_rollout_kernel().endswith("true, false, false, 2>")      # plan-fed, yaw from the dense column
+        # the same with the compute wave evaluating the rows: coefficients on the spot (0, round 3's form, what a full chip uses)
+        # or by LDS-DMA an outer tick ahead (1, what a chip with three workgroups per CU uses): the same bits
         try:
-            for yaw_from in ("scan", "column"):
-                e = eng.fleet(plan, from_plan=True, yaw_from=yaw_from)
-                le, ce = e.rollout(K, state_log=True, cmd_log=True)
-                assert eng.ctx.last_rollout_kernel().endswith("true, false, true>" if yaw_from == "scan" else "true, false, false>")
-                assert torch.equal(le, lb) and torch.equal(ce, cb) and torch.equal(e.state[:26], b.state[:26]) and torch.equal(e.istate, b.istate)
+            for mode, suffix in ((0, ""), (1, ", 1")):
+                eng.ctx.set_option("coeff_dma", mode)
+                for yaw_from in ("scan", "column"):
+                    e = eng.fleet(plan, from_plan=True, yaw_from=yaw_from)
+                    le, ce = e.rollout(K, state_log=True, cmd_log=True)
+                    assert eng.ctx.last_rollout_kernel().endswith(("true, false, true" if yaw_from == "scan" else "true, false, false") + suffix + ">")
+                    assert torch.equal(le, lb) and torch.equal(ce, cb) and torch.equal(e.state[:26], b.state[:26]) and torch.equal(e.istate, b.istate)
+                nl = eng.fleet(plan, from_plan=True)                 # no second wave: modes 0 and 1 only
+                nl.rollout(K)
+                assert eng.ctx.last_rollout_kernel().endswith("false, false, false, true, false, true" + suffix + ">")
+                assert torch.equal(nl.state[:26], b.state[:26]) and torch.equal(nl.istate, b.istate)
         finally:
             eng.ctx.set_option("coeff_dma", -1)
         assert torch.equal(la, lb) and torch.equal(ca, cb) and torch.equal(la, ld) and torch.equal(ca, cd)
@@ -560,6 +566,45 @@ def test_fleet_picks_the_rollout_feed_by_batch_size(eng):
                                         device_loop=False)
     with pytest.raises(ValueError):
         eng.fleet(rows_only, from_plan=True)
+
+
+@pytest.mark.parametrize("F", [7, 8, 10, 13])
+def test_target_rows_by_the_second_wave_in_every_hand_over_mode(eng, nat, F):
+    """PMODE 2 (the second wave owns the cursor and evaluates the target rows a piece per tick): the hand-over of a row through
+    its LDS tile must be ordered before the compute wave's read by a barrier in BOTH slab hand-over modes (end of tick / a
+    third of a tick later), with and without the placeholder wave, for every F >= 7 -- on plans whose segments last one or two
+    rows (the cursor enters a new segment at almost every outer tick: coefficients by LDS-DMA every time), split into launches
+    at odd ticks.  Same bits as the row-fed rollout."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    B, K = 320, 700
+    plan = eng.plan(mo.synthetic_missions(B, 24, 0.4, 1.2), 6.0, 0.05)
+    V = nat.Vehicle.default()
+    V.inner_per_outer = F
+    V.dt_outer = V.dt * F
+    ref = eng.fleet(plan, vehicle=V, from_plan=False)
+    lb, cb = ref.rollout(K, state_log=True, cmd_log=True)
+    try:
+        eng.ctx.set_option("coeff_dma", 2)
+        for late in (0, 1):
+            for idle in (0, 1):
+                eng.ctx.set_option("late_handover", late)
+                eng.ctx.set_option("idle_waves", idle)
+                a = eng.fleet(plan, vehicle=V, from_plan=True)
+                la, ca = a.rollout(K, state_log=True, cmd_log=True)
+                assert eng.ctx.last_rollout_kernel().endswith(", 2>")
+                assert torch.equal(la, lb) and torch.equal(ca, cb), (late, idle)
+                assert torch.equal(a.state[:26], ref.state[:26]) and torch.equal(a.istate, ref.istate)
+                c = eng.fleet(plan, vehicle=V, from_plan=True)
+                done = 0
+                for k in (1, 2, F - 1, F, F + 1, 3 * F + 2, 97):
+                    c.rollout(k, state_log=True)
+                    done += k
+                c.rollout(K - done, state_log=True)
+                assert torch.equal(c.state, a.state) and torch.equal(c.istate, a.istate), (late, idle)
+    finally:
+        for name in ("coeff_dma", "late_handover", "idle_waves"):
+            eng.ctx.set_option(name, -1)
 
 
 @pytest.mark.parametrize("m,velocity,dt,F", [(64, 6.0, 0.05, 3), (20, 3.0, 0.01, 10), (5, 30.0, 0.05, 1), (2, 0.7, 0.02, 7)])

@@ -225,9 +225,8 @@ def test_rollout_aligner_launch_does_not_change_a_bit(nat):
         plan = e.plan(wps, 3.0, 0.01)
         fleet = e.fleet(plan)
         slog, _ = fleet.rollout(K, state_log=True)
-        # (a full chip reloads coefficients through registers: the eight-argument variant; below ~61 000 UAVs the DMA one)
-        assert e.ctx.last_rollout_kernel() in ("control_rollout_kernel<1, 1, true, false, false, true, false, true>",
-                                               "control_rollout_kernel<1, 1, true, false, false, true, false, true, true>")
+        # (a full chip: the compute wave evaluates the target rows, coefficients through registers -- no ninth argument)
+        assert e.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, true, false, true>"
         logs.append((slog, fleet.state.clone(), fleet.istate.clone()))
         del fleet, plan
     assert torch.equal(logs[1][0], logs[0][0]) and torch.equal(logs[1][1], logs[0][1]) and torch.equal(logs[1][2], logs[0][2])

@@ -314,6 +314,36 @@ def test_streaming_sampler_equals_the_one_wave_sampler_bit_for_bit(eng, waves, g
         assert torch.equal(got[1][0], got[waves][0]) and torch.equal(got[1][1], got[waves][1])
 
 
+def test_streaming_sampler_edge_shapes(eng):
+    """The streaming sampler where its item arithmetic is thin: ONE mission of tens of thousands of rows (hundreds of items per
+    wave, the mailbox sequence numbers run long), a batch of one-row and two-row missions (several missions per 64-row chunk:
+    every item partial), more missions per workgroup than the batch has, and the oracle as referee for one of each."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    long_one = np.array([[[0.0, 0.0, -1.0], [120.0, 40.0, -3.0], [60.0, 160.0, -2.0], [-50.0, 90.0, -4.0]]])    # ~45 000 rows at v = 1, dt = 0.01
+    tiny = mo.synthetic_missions(333, 2) * 0.004                                  # legs of ~1 cm: one or two rows per spline
+    for wps, v, dt in ((long_one, 1.0, 0.01), (tiny, 3.0, 0.01), (mo.synthetic_missions(3, 5), 3.0, 0.01)):
+        got = {}
+        for sw, g in ((1, 1), (4, 1), (4, 7), (2, 64), (16, 3)):
+            eng.ctx.set_option("sampler_waves", sw)
+            eng.ctx.set_option("sampler_group", g)
+            try:
+                plan = eng.plan(wps, v, dt)
+                assert eng.take_flags() == [0, 0, 0, 0]
+                got[(sw, g)] = (plan.traj.clone(), plan.first_yaw.clone())
+            finally:
+                eng.ctx.set_option("sampler_waves", 4)
+                eng.ctx.set_option("sampler_group", 1)
+        for key, val in got.items():
+            assert torch.equal(val[0], got[(1, 1)][0]) and torch.equal(val[1], got[(1, 1)][1]), key
+        ref = mo.plan(wps[0], v, dt, method="solve")
+        mine = plan.mission(0)
+        assert mine.shape == ref.shape and np.array_equal(mine[:, 10], ref[:, 10])
+        err = np.max(np.abs(mine - ref), axis=0) / np.maximum(1.0, np.max(np.abs(ref), axis=0))
+        assert err.max() < 1e-5, err
+    assert long_one.shape[0] == 1 and plan is not None
+
+
 def test_streaming_sampler_variants_equal_the_one_wave_sampler(eng):
     """The streaming sampler's other outputs -- dense yaw column, jerk / snap, hit flags of a cuboid, ragged batches --
     against the one-wave-per-mission kernel, bit for bit."""

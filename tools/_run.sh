@@ -1,1 +1,1 @@
-timeout 600 python tools/sampler_stream_ab.py 6 65536 12 1x1,4x1,2x1,8x1,4x2,8x2 2>/dev/null | grep waves_x
+timeout 900 python -m pytest tests/test_gpu_control.py -x -q -m gpu -k "second_wave or corner" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5

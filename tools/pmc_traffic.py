@@ -53,9 +53,9 @@ def collect(counter):
                     if big:
                         name = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0]
                         # the library names a rollout variant by its first eight template arguments and appends the ninth
-                        # (coefficients by LDS-DMA) only when it is true: the same here
-                        if key == "control_rollout" and name.endswith(", false>") and name.count(",") == 8:
-                            name = name[:-len(", false>")] + ">"
+                        # (who evaluates target rows / how coefficients arrive) only when it is not 0: the same here
+                        if key == "control_rollout" and name.endswith(", 0>") and name.count(",") == 8:
+                            name = name[:-len(", 0>")] + ">"
                         per.setdefault((key, name), []).append(float(r["Counter_Value"]))
     return per
 

@@ -5,7 +5,7 @@ import numpy as np, torch
 from oracle import minsnap_oracle as mo
 from uav_ac.fleet import Engine
 eng = Engine("cuda:0")
-for B, m, K in ((130, 3, 2600), (64, 1, 900)):
+for B, m, K in ((130, 3, 2600), (64, 1, 900), (5000, 12, 1200)):
     wps = mo.synthetic_missions(B, m)
     plan = eng.plan(wps, 3.0, 0.01)
     a, b = eng.fleet(plan, from_plan=True), eng.fleet(plan, from_plan=False)

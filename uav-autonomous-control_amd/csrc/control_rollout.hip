@@ -105,6 +105,7 @@ __device__ __forceinline__ void seg_rows_issue(int &r, const int32_t *p) {
     asm volatile("global_load_dword %0, %1, off" : "+v"(r) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void plan_loads_wait(int &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory"); }
+template <int N> __device__ __forceinline__ void store_wave_loads_wait(int &r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory"); }
 
 __device__ __forceinline__ double row_col(const RowRegs &r, int c) {      // c is a compile-time constant
     const u32x4 q = r.q[c >> 1];
@@ -156,7 +157,7 @@ constexpr int poly_tile_doubles(bool yawscan) { return (24 + (yawscan ? 0 : 16))
 // functions (minsnap_yaw.h; the sampler sums the corrections in the same left-to-right order).  Rows before a mission's
 // first heading take P.first_yaw[b].  A cursor that does not match the carried scan (a caller moved it, another kernel
 // advanced it) is caught at launch and the scan is rebuilt from row 0.  No yaw bytes are read or written at all.
-template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN, bool ADMA = false>
+template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN, int PMODE = 0>
 __global__ void __launch_bounds__((LOG_STATE || LOG_CMD || AABB) ? 64 * CW + 128 : 64 * CW)       // compute [+ placeholder] + store
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
                        double *__restrict__ state, int32_t *__restrict__ istate, int B, int K,
@@ -169,6 +170,15 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     // one dependent instruction stream; bounds in lanes + v_readlane were slower still, and it has no registers to hold them).
     constexpr bool WATCH = AABB && !LOG_STATE && !LOG_CMD && CW == SW;
     constexpr bool LOGGING = LOG_STATE || LOG_CMD || WATCH;            // "a second wave takes a slab per tick"
+    // PMODE (plan-fed kernels): who evaluates a target row and how a segment's coefficients reach the LDS tile.
+    //   0  the compute wave; coefficients through registers on the spot (what a full chip without a second wave uses)
+    //   1  the compute wave; coefficients by LDS-DMA an outer tick ahead (see coeffs_dma)
+    //   2  the SECOND wave (TGW): it idles four fifths of every tick at the barrier, so it owns the trajectory cursor, evaluates
+    //      the next target row (Horner, atan2, yaw scan: ~1 200 cycles per outer tick, 6-10 % of the compute wave's tick) while
+    //      the compute wave flies the inner ticks, and hands the row over through a [10][64] LDS tile.
+    constexpr bool ADMA = PMODE == 1;
+    constexpr bool TGW = PMODE == 2;
+    static_assert(!TGW || (POLY && LOGGING), "target rows by the second wave: plan-fed kernels that have one");
     constexpr int NU = 64 * CW;                                        // UAVs per workgroup
     constexpr int NR = (LOG_STATE ? 13 : 0) + (LOG_CMD ? UAVAC_CMD_COLS : 0) + (WATCH ? 3 : 0);
     constexpr int CMD0 = LOG_STATE ? 13 : 0;                           // first command row in a slab
@@ -238,6 +248,111 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         const bool mine = col0 + lane < B;
         int coll = (AABB_HERE && mine) ? istate[2 * sB + col0 + lane] : 0;
         if (AABB_HERE) settle(coll);               // landed before the tick loop (see above)
+        // ---- TGW: this wave owns the trajectory cursor of its 64 UAVs (the same arithmetic, in the same order, as the compute
+        // wave's in the other modes: E = evaluate the row under the cursor, A = advance; E0 A0 E1 A1 ... -- here E runs one
+        // outer tick AHEAD and its update of the yaw scan stays pending until the compute wave has consumed the row, so that
+        // what a launch saves is exactly what the other modes save)
+        double *tgt = slab + (size_t)2 * NR * NU + (size_t)CW * poly_tile_doubles(YAWSCAN) + lane;        // tgt[j * 64], j = 0 .. 9
+        double *tile2 = slab + (size_t)2 * NR * NU;                                                       // the coefficient tile, [12][64][2]
+        double *cf2 = tile2 + 2 * lane, *yw2 = tile2 + 24 * 64 + lane;
+        const unsigned tile2_lds = TGW ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)tile2) : 0u;
+        const int bb2 = mine ? col0 + lane : B - 1;
+        int t_idx = 0, t_phase = 0, t_nrows = 0, t_pm = 1, t_seg = 0, t_rin = 0, t_srows = 0, t_srows_nx = 0, t_ybase = 0;
+        int t_yhas = 0, t_yhas_n = 0;
+        double t_yprev = 0.0, t_ysum = 0.0, t_yprev_n = 0.0, t_ysum_n = 0.0, t_first_yaw = 0.0;
+        const int32_t *t_seg_rows = nullptr;
+        const double *t_coeffs = nullptr, *t_yaws = nullptr;
+        auto t_load_coeffs = [&](int s_) {           // through registers, on the spot: launch start, the scan's rebuild, empty segments
+            const double *src = t_coeffs + 24 * s_;
+#pragma unroll
+            for (int j = 0; j < 24; ++j) cf2[minsnap_coeff_index<0>(j)] = src[j];
+        };
+        // E: the row under the cursor -> the target tile, in four pieces (one axis each, then the yaw) spread over four ticks: in
+        // one piece it is ~1 300 cycles of a 2 000-cycle tick, and a second wave that is late at the barrier stalls the compute
+        // wave (1.30 against 1.26 ms per 1 000 ticks at 65 536 UAVs before the split); the scan's update stays pending
+        double t_px = 0, t_py = 0, t_pz = 0, t_vx = 0, t_vy = 0, t_vz = 0, t_ax = 0, t_ay = 0, t_az = 0;
+        auto t_eval_axis = [&](int a_) {
+            const double t_ = (double)t_rin * P.dt;
+            if (a_ == 0) minsnap_eval_axis<0>(cf2, 0, t_, t_px, t_vx, t_ax);
+            else if (a_ == 1) minsnap_eval_axis<0>(cf2, 1, t_, t_py, t_vy, t_ay);
+            else minsnap_eval_axis<0>(cf2, 2, t_, t_pz, t_vz, t_az);
+        };
+        auto t_eval_yaw_and_hand_over = [&]() {
+            double yaw_;
+            t_yhas_n = t_yhas; t_yprev_n = t_yprev; t_ysum_n = t_ysum;
+            if (YAWSCAN) {
+                const bool yvalid = uavac_yaw::has_heading(t_vx, t_vy);
+                const double yang = yvalid ? atan2(t_vy, t_vx) : 0.0;
+                const double ycum = (yvalid && t_yhas) ? t_ysum + uavac_yaw::unwrap_correction(yang - t_yprev) : t_ysum;
+                yaw_ = yvalid ? yang + ycum : (t_yhas ? t_yprev + t_ysum : t_first_yaw);
+                if (t_idx + 1 < t_nrows) {
+                    if (yvalid) { t_yhas_n = 1; t_yprev_n = yang; }
+                    t_ysum_n = ycum;
+                }
+            } else {
+                yaw_ = yw2[(t_idx - t_ybase) * 64];
+            }
+            tgt[0] = t_px; tgt[64] = t_py; tgt[128] = t_pz; tgt[192] = t_vx; tgt[256] = t_vy; tgt[320] = t_vz;
+            tgt[384] = t_ax; tgt[448] = t_ay; tgt[512] = t_az; tgt[576] = yaw_;
+        };
+        auto t_eval = [&]() { t_eval_axis(0); t_eval_axis(1); t_eval_axis(2); t_eval_yaw_and_hand_over(); };      // launch start: all at once
+        if (TGW) {
+            const int64_t off2 = row_offsets[bb2];
+            t_nrows = (int)(row_offsets[bb2 + 1] - off2);
+            t_idx = istate[0 * sB + bb2];
+            t_phase = istate[1 * sB + bb2] % V.F;
+            t_pm = P.m;
+            size_t seg0 = (size_t)bb2 * P.m;
+            if (P.seg_offsets) {
+                seg0 = (size_t)P.seg_offsets[bb2];
+                const int64_t n_ = P.seg_offsets[bb2 + 1] - P.seg_offsets[bb2];
+                t_pm = (int)(n_ < 1 ? 1 : (n_ > P.m ? P.m : n_));
+            }
+            t_seg_rows = P.seg_rows + seg0;
+            t_coeffs = P.coeffs + seg0 * 24;
+            t_yaws = YAWSCAN ? nullptr : P.yaw + off2;
+            if (t_nrows > 0) {
+                t_idx = min(max(t_idx, 0), t_nrows - 1);
+                if (YAWSCAN) {
+                    t_first_yaw = P.first_yaw[bb2];
+                    const double scan_row = state[26 * sB + bb2];
+                    if (scan_row == (double)t_idx) {
+                        t_yhas = state[27 * sB + bb2] != 0.0;
+                        t_yprev = state[28 * sB + bb2];
+                        t_ysum = state[29 * sB + bb2];
+                    } else {
+                        // the cursor is not where the carried scan stands: rebuild it from the mission's first row (rare)
+                        int s_ = 0, r_ = 0, n_ = t_seg_rows[0];
+                        t_load_coeffs(0);
+                        for (int row = 0; row < t_idx; ++row) {
+                            while (r_ >= n_ && s_ + 1 < t_pm) { r_ -= n_; ++s_; n_ = t_seg_rows[s_]; t_load_coeffs(s_); }
+                            double x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_;
+                            minsnap_eval_row<0>(cf2, (double)r_ * P.dt, x_, y_, z_, vx_, vy_, vz_, ax_, ay_, az_);
+                            if (uavac_yaw::has_heading(vx_, vy_)) {
+                                const double a_ = atan2(vy_, vx_);
+                                if (t_yhas) t_ysum = t_ysum + uavac_yaw::unwrap_correction(a_ - t_yprev);
+                                t_yhas = 1;
+                                t_yprev = a_;
+                            }
+                            ++r_;
+                        }
+                    }
+                }
+                t_rin = t_idx;
+                t_srows = t_seg_rows[0];
+                while (t_seg + 1 < t_pm && t_rin >= t_srows) { t_rin -= t_srows; ++t_seg; t_srows = t_seg_rows[t_seg]; }
+                t_load_coeffs(t_seg);
+                t_srows_nx = t_seg_rows[min(t_seg + 1, t_pm - 1)];
+                if (!YAWSCAN) {
+                    t_ybase = t_idx;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) yw2[j * 64] = t_yaws[min(t_ybase + j, t_nrows - 1)];
+                }
+                t_eval();
+            }
+            settle(t_srows_nx); settle(t_idx); settle(t_phase); settle(t_yprev); settle(t_ysum); settle(t_first_yaw);
+            lds_barrier();                         // the first target row is in its tile (the compute wave waits here too)
+        }
 #ifdef UAVAC_DIAG_STAMPS
         long long dg_wait = 0, dg_issue = 0;
         const long long dg_t0 = DIAG_NOW();
@@ -312,7 +427,57 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 #ifdef UAVAC_DIAG_STAMPS
             dg_issue += DIAG_NOW() - dg_b;
 #endif
+            if (TGW) {
+                constexpr int kStoresPerTick = (LOG_STATE ? 13 : 0) + (LOG_CMD ? UAVAC_CMD_COLS : 0);
+                if (t_phase == 0 && t_nrows > 0) {
+                    // the compute wave consumed the tile's row in the tick whose slab has just left: commit its share of the yaw
+                    // scan and advance the cursor (main.py:61).  A cursor that enters a new segment asks for its coefficients
+                    // (LDS-DMA) and for the row count of the segment after (in flight for a whole segment).  This wave has log
+                    // stores in flight all the time and vmcnt counts loads and stores in issue order: waiting for "all but the
+                    // youngest tick's stores" covers a load that is older than that without waiting for the newest stores.
+                    t_yhas = t_yhas_n; t_yprev = t_yprev_n; t_ysum = t_ysum_n;
+                    if (t_idx + 1 < t_nrows) {
+                        ++t_idx;
+                        if (++t_rin >= t_srows && t_seg + 1 < t_pm) {      // next segment (skipping empty ones, like the sampler's segment_of)
+                            store_wave_loads_wait<kStoresPerTick>(t_srows_nx);
+                            t_rin -= t_srows; ++t_seg; t_srows = t_srows_nx;
+                            while (t_rin >= t_srows && t_seg + 1 < t_pm) { t_rin -= t_srows; ++t_seg; t_srows = t_seg_rows[t_seg]; }
+                            coeffs_dma(t_coeffs + 24 * t_seg, tile2_lds);
+                            seg_rows_issue(t_srows_nx, t_seg_rows + min(t_seg + 1, t_pm - 1));
+                        }
+                        if (!YAWSCAN && t_idx - t_ybase == 16) {
+                            t_ybase = t_idx;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) yw2[j * 64] = t_yaws[min(t_ybase + j, t_nrows - 1)];
+                        }
+                    }
+                } else if (t_phase >= 1 && t_phase <= 4 && t_nrows > 0) {
+                    // the row of the NEXT outer tick, a piece per tick over the four ticks that follow -- at the priority of a
+                    // background job, a compute wave may share this SIMD.  (The coefficients asked for a tick ago are older than
+                    // this tick's stores.)  The hand-over in the iteration of phase 4 is ordered before the compute wave's read at
+                    // the start of its next phase-0 tick by a barrier for F >= 7 in either hand-over mode: with the late
+                    // hand-over the compute wave calls barrier j in the middle of tick j + 1, so this wave's iteration k runs
+                    // between the middle of tick k + 1 and the middle of tick k + 2.
+                    __builtin_amdgcn_s_setprio(0);
+                    if (t_phase == 1) { store_wave_loads_wait<kStoresPerTick>(t_srows_nx); t_eval_axis(0); }
+                    else if (t_phase == 2) t_eval_axis(1);
+                    else if (t_phase == 3) t_eval_axis(2);
+                    else t_eval_yaw_and_hand_over();
+                    __builtin_amdgcn_s_setprio(3);
+                }
+                t_phase = (t_phase + 1 == V.F) ? 0 : t_phase + 1;
+            }
         }
+        if (TGW && mine) {                         // what the other modes' compute wave saves: cursor and the scan as it stands before it
+            istate[0 * sB + col0 + lane] = t_idx;
+            if (YAWSCAN) {
+                state[26 * sB + col0 + lane] = (double)t_idx;
+                state[27 * sB + col0 + lane] = t_yhas ? 1.0 : 0.0;
+                state[28 * sB + col0 + lane] = t_yprev;
+                state[29 * sB + col0 + lane] = t_ysum;
+            }
+        }
+        if (TGW) store_wave_loads_wait<0>(t_srows_nx);       // nothing stays in flight into the tile the next pass reloads
 #ifdef UAVAC_DIAG_STAMPS
         if (lane == 0 && blockIdx.x < 8192) {
             g_uavac_diag[blockIdx.x * 8 + 3] = dg_issue;
@@ -420,7 +585,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     // YAWSCAN: the carried scan (state rows 26-29)
     int yhas = 0;
     double yprev = 0.0, ysum = 0.0, first_yaw = 0.0;
-    if (POLY && nrows > 0) {
+    if (POLY && !TGW && nrows > 0) {
         idx = min(max(idx, 0), nrows - 1);
         if (YAWSCAN) {
             first_yaw = P.first_yaw[bb];
@@ -466,6 +631,9 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     const double qn2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
     double inv_n2 = (fabs(qn2 - 1.0) < 1.0e-12) ? 1.0 : 1.0 / qn2;
 
+    // TGW: the target row of the next outer tick, put there by the second wave (which also owns the cursor)
+    const double *tgt = slab + (size_t)2 * NR * NU + (size_t)CW * poly_tile_doubles(YAWSCAN) + (tid & 63);
+    if (TGW) lds_barrier();                        // the first row is in the tile
 #ifdef UAVAC_DIAG_STAMPS
     long long dgc_wait = 0, dgc_seg[4] = {0, 0, 0, 0}, dgc_out[4] = {0, 0, 0, 0};
     const long long dgc_t0 = DIAG_NOW();
@@ -478,7 +646,13 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 #ifdef UAVAC_DIAG_STAMPS
             const long long dg_o0 = DIAG_NOW();
 #endif
-            if (POLY) {
+#ifdef UAVAC_DIAG_SKIP_TARGET     // DIAGNOSTIC (wrong results): what a tick costs when somebody else evaluates the target row
+            if (POLY && k >= V.F) { tg_x = px; tg_y = py; tg_z = pz; tg_vx = 0; tg_vy = 0; tg_vz = 0; tg_ax = 0; tg_ay = 0; tg_az = 0; tg_yaw = first_yaw; } else
+#endif
+            if (TGW) {
+                tg_x = tgt[0]; tg_y = tgt[64]; tg_z = tgt[128]; tg_vx = tgt[192]; tg_vy = tgt[256]; tg_vz = tgt[320];
+                tg_ax = tgt[384]; tg_ay = tgt[448]; tg_az = tgt[512]; tg_yaw = tgt[576];
+            } else if (POLY) {
                 if (ADMA) plan_loads_wait(srows_nx);            // coefficients (and row count) asked for an outer tick ago have landed
                 minsnap_eval_row<CST>(cf, (double)rin * plan_dt, tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az);
                 if (YAWSCAN) {
@@ -529,7 +703,9 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 #endif
             // next row (main.py:61), consumed F ticks from now; issued last so that nothing in this block
             // still reads the registers it overwrites
-            if (POLY) {
+            if (TGW) {
+                // (the second wave advances the cursor)
+            } else if (POLY) {
                 if (idx + 1 < nrows) {                    // main.py:61: the cursor stops on the last row
                     ++idx;
                     if (++rin >= srows) {                 // next segment (skipping empty ones, like the sampler's segment_of)
@@ -645,11 +821,11 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     state[21 * sB + b] = integ;
     state[22 * sB + b] = thrust_cmd;
     state[23 * sB + b] = pc; state[24 * sB + b] = qc; state[25 * sB + b] = rc;
-    istate[0 * sB + b] = idx;
+    if (!TGW) istate[0 * sB + b] = idx;            // (TGW: the second wave owns and saves the cursor)
     istate[1 * sB + b] = inner;
     if (!AABB || BOX_HERE) istate[2 * sB + b] = collided;
     if (GROUND) istate[3 * sB + b] = gbits;
-    if (POLY && YAWSCAN) {
+    if (POLY && YAWSCAN && !TGW) {
         state[26 * sB + b] = (double)idx;
         state[27 * sB + b] = yhas ? 1.0 : 0.0;
         state[28 * sB + b] = yprev;
@@ -692,7 +868,7 @@ __global__ void __launch_bounds__(256) rollout_align_kernel() {}
 // per 1 000 ticks against 1.33 ms: the per-tick barrier then couples eight waves; round 3 measured two + two waves per 128 UAVs
 // slower at every batch size as well, profiles/r03_rollout_shapes_wide_workgroup.jsonl.  The kernel keeps its CW / SW
 // parameters; only <1, 1> is instantiated.)
-template <bool LS, bool LC, bool AB, bool POLY, bool GR, bool YS, bool ADMA = false>
+template <bool LS, bool LC, bool AB, bool POLY, bool GR, bool YS, int PMODE = 0>
 void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64_t *row_offsets, double *state,
                   int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                   const PlanRef &P) {
@@ -710,8 +886,8 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
         else n_idle = (4 * n_tiles > ctx->n_simds && 2 * n_tiles <= ctx->n_simds) ? 1 : 0;
     }
     const int threads = NU + (LOGGING ? 64 * (1 + n_idle) : 0);
-    const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0));
-    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS, ADMA>;
+    const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0) + (PMODE == 2 ? 10 * NU : 0));
+    auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS, PMODE>;
     if (lds + (size_t)ctx->lds_pad > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)ctx->lds_pad));
     // With a second wave per workgroup the launch holds at most one workgroup per SIMD; a batch with more 64-UAV tiles than
@@ -730,11 +906,6 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     const int late = ctx->late_handover >= 0 ? ctx->late_handover
                                              : ((cols > 20 * ctx->n_simds && cols < 40 * ctx->n_simds) ? 0 : 1);
     const size_t pitch = (LS || LC) ? (ctx->log_pitch > 0 ? (size_t)ctx->log_pitch : (size_t)B) : (size_t)B;
-    // Plan-fed: how a lane's next segment reaches the coefficient tile.  By LDS-DMA, asynchronously (see coeffs_dma), while the
-    // chip is not full -- per 1 000 logged ticks against the reload through registers, same process, same buffers
-    // (tools/rollout_ab.py, m = 12): 0.834 / 0.852 ms at 16 384 UAVs, 0.891 / 0.984 at 32 768, 0.997 / 1.055 at 49 152 -- and
-    // through registers on the full chip, where a launch is bound by its log stream and the twelve DMA instructions per
-    // segment change are only in the way: 1.27 / 1.25 ms at 65 536.  Same bits either way.
     if (LOGGING && ctx->rollout_align)
         hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(threads), 0, ctx->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds + (size_t)ctx->lds_pad, ctx->stream, V, traj, row_offsets, state, istate,
@@ -742,7 +913,7 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     auto tf = [](bool v) { return v ? "true" : "false"; };
     char name[176];
     snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s%s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
-             tf(GR), tf(YS), ADMA ? ", true" : "");
+             tf(GR), tf(YS), PMODE == 1 ? ", 1" : (PMODE == 2 ? ", 2" : ""));
     ctx->last_rollout = name;
     // vector registers of that kernel as the loaded code object has them (once per variant): above 256 a SIMD holds ONE
     // wave of it and the launch runs at 0.65x -- a toolchain that crosses the line shows up here and in bench.py's line
@@ -759,31 +930,39 @@ void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int
                     int32_t *istate, int B, int K, double *state_log, double *cmd_log, const double *aabbs, int n_obs,
                     const PlanRef *plan) {
 #define UAVAC_SHAPE_ARGS ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs
-    // Plan-fed: how a lane's next segment reaches the coefficient tile.  By LDS-DMA, asynchronously (see coeffs_dma), while the
-    // chip is not full -- per 1 000 logged ticks against the reload through registers, same process, same buffers
-    // (tools/rollout_ab.py, m = 12): 0.834 / 0.852 ms at 16 384 UAVs, 0.891 / 0.984 at 32 768, 0.997 / 1.055 at 49 152 -- and
-    // through registers on the full chip, where a launch is bound by its log stream and the twelve DMA instructions per
-    // segment change are only in the way: 1.27 / 1.25 ms at 65 536.  Same bits either way.  (A template parameter, not a
-    // branch: with both forms in one kernel the plan-fed variants need 257-260 vector registers.)
+    // Plan-fed kernels, PMODE (see the kernel): who evaluates the target rows, how coefficients reach the LDS tile.  Per 1 000
+    // logged ticks, same process and buffers (tools/rollout_ab.py, m = 12), mode 2 / 1 / 0 (= round 3):
+    //     16 384 UAVs 0.792 / 0.834 / 0.852 ms     32 768  0.879 / 0.891 / 0.984     49 152  1.011 / 0.997 / 1.055-1.078
+    //     65 536      1.297 / 1.27 / 1.25-1.26
+    // * up to two workgroups per CU every working wave has a SIMD of its own and the second wave's idle time is free: it
+    //   evaluates the rows (2; needs a second wave, and F >= 7 inner ticks per outer tick: the row is evaluated in four pieces,
+    //   one to four ticks after the cursor moved);
+    // * with three or four workgroups per CU a second wave shares its SIMD with a compute wave: the compute wave evaluates, its
+    //   coefficients arrive by LDS-DMA (1) -- also the form of the kernels without a second wave while the chip is not full;
+    // * a full chip is bound by its log stream and the twelve DMA instructions per segment change are only in the way: through
+    //   registers, on the spot (0).
+    // Same bits in every mode.  (Template parameters, not branches: with two forms in one kernel the plan-fed variants need
+    // 257-260 vector registers.)  Option "coeff_dma": -1 = as above, 0 / 1 / 2 = that mode where the kernel has it.
     constexpr bool LOGGING = LS || LC || AB;
     const int tiles = (B + 63) / 64, in_flight = (LOGGING && tiles > ctx->n_simds) ? ctx->n_simds : tiles;
-    const bool dma = plan && (ctx->coeff_dma >= 0 ? ctx->coeff_dma != 0 : in_flight * 64 < 60 * ctx->n_simds);
+    int mode = 0;
+    if (plan) {
+        if (ctx->coeff_dma >= 0) mode = ctx->coeff_dma > 2 ? 2 : ctx->coeff_dma;
+        else mode = in_flight * 64 >= 60 * ctx->n_simds ? 0 : (2 * in_flight <= ctx->n_simds ? 2 : 1);
+        if (mode == 2 && (!LOGGING || V.F < 7)) mode = 1;
+    }
+#define UAVAC_LAUNCH_MODE(GR_, YS_)                                                                     \
+    do {                                                                                                \
+        if (mode == 1) launch_shape<LS, LC, AB, true, GR_, YS_, 1>(UAVAC_SHAPE_ARGS, *plan);            \
+        else if (mode == 2) {                                                                           \
+            if constexpr (LOGGING) launch_shape<LS, LC, AB, true, GR_, YS_, 2>(UAVAC_SHAPE_ARGS, *plan); \
+        } else launch_shape<LS, LC, AB, true, GR_, YS_, 0>(UAVAC_SHAPE_ARGS, *plan);                    \
+    } while (0)
     if (plan && !plan->yaw) {                       // the rollout scans the yaw itself
-        if (dma) {
-            if (V.ground) launch_shape<LS, LC, AB, true, true, true, true>(UAVAC_SHAPE_ARGS, *plan);
-            else launch_shape<LS, LC, AB, true, false, true, true>(UAVAC_SHAPE_ARGS, *plan);
-        } else {
-            if (V.ground) launch_shape<LS, LC, AB, true, true, true>(UAVAC_SHAPE_ARGS, *plan);
-            else launch_shape<LS, LC, AB, true, false, true>(UAVAC_SHAPE_ARGS, *plan);
-        }
+        if (V.ground) UAVAC_LAUNCH_MODE(true, true); else UAVAC_LAUNCH_MODE(false, true);
     } else if (plan) {
-        if (dma) {
-            if (V.ground) launch_shape<LS, LC, AB, true, true, false, true>(UAVAC_SHAPE_ARGS, *plan);
-            else launch_shape<LS, LC, AB, true, false, false, true>(UAVAC_SHAPE_ARGS, *plan);
-        } else {
-            if (V.ground) launch_shape<LS, LC, AB, true, true, false>(UAVAC_SHAPE_ARGS, *plan);
-            else launch_shape<LS, LC, AB, true, false, false>(UAVAC_SHAPE_ARGS, *plan);
-        }
+        if (V.ground) UAVAC_LAUNCH_MODE(true, false); else UAVAC_LAUNCH_MODE(false, false);
+#undef UAVAC_LAUNCH_MODE
     } else {
         if (V.ground) launch_shape<LS, LC, AB, false, true, false>(UAVAC_SHAPE_ARGS, PlanRef{});
         else launch_shape<LS, LC, AB, false, false, false>(UAVAC_SHAPE_ARGS, PlanRef{});

@@ -33,12 +33,12 @@ __device__ __forceinline__ void minsnap_eval_row(const double *c, double t, doub
 template <int STRIDE>
 __device__ __forceinline__ void minsnap_eval_axis(const double *c, int a, double t, double &p, double &v, double &acc) {
     double d1 = 0, d2 = 0;
-    p = c[(21 + a) * STRIDE];
+    p = c[minsnap_coeff_index<STRIDE>(21 + a)];
 #pragma unroll
     for (int i = 6; i >= 0; --i) {
         d2 = fma(d2, t, d1);
         d1 = fma(d1, t, p);
-        p = fma(p, t, c[(3 * i + a) * STRIDE]);
+        p = fma(p, t, c[minsnap_coeff_index<STRIDE>(3 * i + a)]);
     }
     v = d1;
     acc = 2.0 * d2;

@@ -310,7 +310,7 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
     } else if (n == "late_handover") {
         ctx->late_handover = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "coeff_dma") {
-        ctx->coeff_dma = value < 0 ? -1 : (value ? 1 : 0);
+        ctx->coeff_dma = value < 0 ? -1 : (value > 2 ? 2 : value);
     } else if (n == "idle_waves") {
         ctx->idle_waves = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "lds_pad") {

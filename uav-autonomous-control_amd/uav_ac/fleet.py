@@ -723,7 +723,7 @@ class Engine:
 
 class Fleet:
     """B UAVs tracking the B missions of a Plan: batched TrajectoryController + free-flight simulation."""
-    PLAN_FED_MIN_BATCH = 26624
+    PLAN_FED_MIN_BATCH = 18432
 
     def __init__(self, engine: Engine, plan: Plan, vehicle=None, hover=True, positions=None, from_plan=None,
                  yaw_from: str = "scan"):
@@ -736,11 +736,12 @@ class Fleet:
         # kernel from plan.first_yaw, or read from the dense column plan.yaw when only that exists)
         # instead of the sampled rows.  Same bits either way.  Default: when the plan carries them (a RaggedPlan does
         # not) and a CU holds more than one workgroup -- measured per 1 000 logged ticks on an MI355X, plan-fed / row-fed
-        # (round 4, coefficients by LDS-DMA below a full chip): B = 16 384 0.838 / 0.761 ms, 24 576 0.893 / 0.878, 28 672
-        # 0.895 / 0.917, 32 768 0.897 / 0.919, 40 960 0.947 / 1.143, 65 536 1.257 / 1.419, 131 072 2.53 / 2.92
-        # (tools/plan_vs_rows.py, profiles/r04_plan_vs_rows.txt).  With one workgroup per CU evaluating rows costs more than
-        # reading them; from two up, the row-fed kernel's 64 scattered row loads per wave and outer tick share the CU's
-        # address path with the store waves' log stream (profiles/r04_tick_stamps_*.jsonl) and reading loses.
+        # (round 4: target rows by the second wave up to two workgroups per CU, coefficients by LDS-DMA above, through
+        # registers on a full chip): B = 16 384 0.791 / 0.759 ms, 20 480 0.823 / 0.852, 24 576 0.864 / 0.877, 32 768
+        # 0.883 / 0.921, 40 960 0.921 / 1.102, 65 536 1.247 / 1.475, 131 072 2.48 / 2.82 (tools/plan_vs_rows.py,
+        # profiles/r04_plan_vs_rows.txt).  With one workgroup per CU reading rows is still a little cheaper than having them
+        # evaluated; from two up, the row-fed kernel's 64 scattered row loads per wave and outer tick share the CU's address
+        # path with the store waves' log stream (profiles/r04_tick_stamps_*.jsonl) and reading loses.
         # a Plan (one segment count for the whole batch) or a RaggedBatch (seg_offsets); a RaggedPlan has rows only
         can = (hasattr(plan, "coeffs") and (hasattr(plan, "m") or hasattr(plan, "seg_offsets")) and
                (getattr(plan, "first_yaw", None) is not None or getattr(plan, "yaw", None) is not None))
