@@ -122,7 +122,8 @@ const char *uavac_build_info(void);
  * (16 385 .. 32 768 UAVs).  "coeff_dma": -1 (default: chosen per launch), 0, 1, 2 = the plan-fed rollout's mode: 0 the compute
  * wave evaluates target rows and reloads a segment's coefficients through registers on the spot; 1 the same with the
  * coefficients arriving by LDS-DMA an outer tick ahead; 2 the second (store) wave owns the cursor and evaluates the rows in
- * its idle time (kernels that have one; inner_per_outer >= 7).  Same bits in every mode.  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
+ * its idle time (kernels that have one; inner_per_outer >= 7).  Same bits in every mode.  "solve_park": -1 (default: chosen per launch), 0, 1 = the coefficient solve parks its forward sweep in the HBM
+ * workspace / in LDS (when (m - 1) x 14 KB fit; same bits).  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
  * chunk-streaming sampler, "sampler_group": 1 (default) .. 64 = consecutive missions per workgroup;
  * "sampler_waves" 1 = the one-wave-per-mission sampler (same rows bit for bit; faster into some row
  * buffers, slower into most: DESIGN K2).

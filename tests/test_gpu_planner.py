@@ -42,6 +42,28 @@ def host_plan(ctx, wps, velocity, dt):
     return coeffs, times, seg_rows, offs, traj
 
 
+@pytest.mark.parametrize("m", [2, 5, 8, 11, 12])
+def test_solve_parked_in_lds_equals_solve_parked_in_hbm(eng, m):
+    """Option "solve_park": the block-Thomas forward sweep keeps [Ut | rt] in the wave's LDS when (m - 1) x 14 KB fit (m <= 11)
+    instead of the HBM workspace -- same arithmetic, same coefficients bit for bit, uniform and ragged batches; m = 12 does not
+    fit and silently stays in HBM."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(200, m)
+    ragged = [w[: 2 + (i % m)] for i, w in enumerate(wps)]
+    got = {}
+    try:
+        for park in (0, 1):
+            eng.ctx.set_option("solve_park", park)
+            plan = eng.plan(wps, 3.0, 0.01)
+            rb = eng.plan_ragged(ragged, 3.0, 0.01)
+            got[park] = (plan.coeffs.clone(), plan.traj.clone(), rb.coeffs.clone(), rb.traj.clone())
+    finally:
+        eng.ctx.set_option("solve_park", -1)
+    for x, y in zip(got[0], got[1]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("B", [3, 9, 40])
 def test_host_twins_move_one_piece_several_pieces_and_more_than_a_megabyte(ctx, eng, B):
     """The host-pointer twins stage pageable buffers through a pinned ping-pong buffer in 256 KiB pieces (two in flight) up to

@@ -177,7 +177,9 @@ constexpr int TB = 64;          // lanes (missions) per workgroup = one wave
 // waypoints, times and coefficients of the batch lie back to back.  Lanes then run different numbers of knots; the backward
 // sweep counts segments from each mission's own end (lane l handles segment m_l - 1 - i in step i), so that the 64 x 24
 // transpose still moves one segment of every mission that has one left.
-template <bool RAGGED>
+// PARK_LDS: the forward sweep parks [Ut | rt] in the wave's own LDS ([m - 1][28][64] doubles, dynamic) instead of the HBM
+// workspace -- when it fits (m <= 8 at 100 KB per wave) and the batch is small enough for that to pay (see the launcher).
+template <bool RAGGED, bool PARK_LDS = false>
 __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__restrict__ wp,
                                                              const double *__restrict__ times, int B, int m_uniform,
                                                              double *__restrict__ ws, double *__restrict__ coeffs,
@@ -196,6 +198,7 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
         if (!__any(b_ < B && active[b_] != 0)) return;
     }
     __shared__ double stage[TB * 25];                 // one segment's 24 coefficients per mission (+1 pad)
+    extern __shared__ double park_lds[];              // PARK_LDS: [m_uniform - 1][28][64]
     __shared__ int64_t seg0_of[RAGGED ? TB : 1];      // ragged: first segment and segment count of every mission of the wave
     __shared__ int m_of[RAGGED ? TB : 1];
     const int lane = threadIdx.x;
@@ -204,6 +207,11 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     const bool live = b < B;
     const int bb = live ? b : B - 1;
     const size_t sB = (size_t)B;
+    // where knot k's parked block lives and how far apart its 28 values are
+    const size_t pst = PARK_LDS ? (size_t)TB : sB;
+    auto park_at = [&](int k_) -> double * {
+        return PARK_LDS ? park_lds + (size_t)k_ * 28 * TB + threadIdx.x : ws + ((size_t)k_ * 28) * sB + (b0 + (int)threadIdx.x < B ? b0 + (int)threadIdx.x : B - 1);
+    };
     int m = m_uniform;
     const double *w = wp + (size_t)bb * (m_uniform + 1) * 3;
     const double *tm = times + (size_t)bb * m_uniform;
@@ -275,13 +283,13 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
                 }
             }
             ok = solve4(S, R) && ok;
-            double *o = ws + ((size_t)kk * 28) * sB + bb;
+            double *o = park_at(kk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (live) o[(size_t)(i * 4 + j) * sB] = R[i][j]; }
+                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (PARK_LDS || live) o[(size_t)(i * 4 + j) * pst] = R[i][j]; }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (live) o[(size_t)(16 + i * 3 + a) * sB] = R[i][4 + a]; }
+                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (PARK_LDS || live) o[(size_t)(16 + i * 3 + a) * pst] = R[i][4 + a]; }
             }
             prev = cur;
         }
@@ -311,10 +319,10 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     // on their way while the segment before is computed: [Ut | rt] of knot s - 1, start waypoint and duration of segment s
     double nxt[28], nw[3], nt;
     {
-        const double *o = ws + ((size_t)(nk >= 1 ? nk - 1 : 0) * 28) * sB + bb;
+        const double *o = park_at(nk >= 1 ? nk - 1 : 0);
         if (nk >= 1) {
 #pragma unroll
-            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * sB];
+            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) nw[a] = w[3 * (m - 1) + a];
@@ -330,9 +338,9 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
         const double p0[3] = {nw[0], nw[1], nw[2]};
         if (step > 0) flush(step - 1);                  // reads the stage before this step overwrites it (LDS is in order)
         if (s >= 2) {
-            const double *o = ws + ((size_t)(s - 2) * 28) * sB + bb;
+            const double *o = park_at(s - 2);
 #pragma unroll
-            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * sB];
+            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
         }
         if (s >= 1) {
 #pragma unroll
@@ -397,7 +405,29 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
         UAVAC_HIP(ctx, hipMalloc(&ctx->d_ws, sizeof(double) * need));
         ctx->ws_cap = need;
     }
-    if (seg_offsets)
+    // Parking in LDS (north_star's "LDS-staged" solve): (m - 1) * 14 336 bytes per wave, so m <= 11 fits the CU's 160 KB at all and
+    // a CU holds floor(144 KB / that) waves at a time instead of the four the HBM-parked kernel runs (one per SIMD) -- with more
+    // waves than that the launch goes round after round.  Measured (tools/solve_time.py, profiles/r04_solve_park.txt); the
+    // launcher takes LDS where that was faster: the whole batch resident at once.  Option "solve_park": -1 auto, 0 HBM, 1 LDS.
+    const size_t park = (size_t)(m > 1 ? m - 1 : 0) * 28 * TB * sizeof(double);
+    const size_t static_lds = sizeof(double) * TB * 25 + (seg_offsets ? TB * 12 : 12);
+    const bool fits = m > 1 && park + static_lds <= (size_t)150 * 1024;
+    const int waves = (B + TB - 1) / TB, cus = ctx->n_simds / 4;
+    const int per_cu = fits ? (int)(((size_t)156 * 1024) / (park + static_lds)) : 0;
+    const bool lds_park = fits && (ctx->solve_park >= 0 ? ctx->solve_park != 0 : waves <= cus * (per_cu < 4 ? per_cu : 4));
+    if (lds_park) {
+        if (seg_offsets) {
+            auto kern = minsnap_solve_bt_kernel<true, true>;
+            if (park > 48 * 1024) UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)park));
+            hipLaunchKernelGGL(kern, dim3(waves), dim3(TB), park, ctx->stream, wp, times, B, m, ctx->d_ws, coeffs, status, ctx->d_flags,
+                               seg_offsets, guard_rows, guard_capacity, active);
+        } else {
+            auto kern = minsnap_solve_bt_kernel<false, true>;
+            if (park > 48 * 1024) UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)park));
+            hipLaunchKernelGGL(kern, dim3(waves), dim3(TB), park, ctx->stream, wp, times, B, m, ctx->d_ws, coeffs, status, ctx->d_flags,
+                               seg_offsets, guard_rows, guard_capacity, active);
+        }
+    } else if (seg_offsets)
         hipLaunchKernelGGL(minsnap_solve_bt_kernel<true>, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
                            ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets, guard_rows, guard_capacity, active);
     else

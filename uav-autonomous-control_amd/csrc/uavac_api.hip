@@ -309,6 +309,8 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
         ctx->log_pitch = value;
     } else if (n == "late_handover") {
         ctx->late_handover = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "solve_park") {
+        ctx->solve_park = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "coeff_dma") {
         ctx->coeff_dma = value < 0 ? -1 : (value > 2 ? 2 : value);
     } else if (n == "idle_waves") {
