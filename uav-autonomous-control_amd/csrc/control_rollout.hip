@@ -261,7 +261,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
         const unsigned tile2_lds = TGW ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)tile2) : 0u;
         const int bb2 = mine ? col0 + lane : B - 1;
         int t_idx = 0, t_phase = 0, t_nrows = 0, t_pm = 1, t_seg = 0, t_rin = 0, t_srows = 0, t_srows_nx = 0, t_ybase = 0;
-        int t_yhas = 0, t_yhas_n = 0;
+        int t_yhas = 0, t_yhas_n = 0, t_asked = 0;
         double t_yprev = 0.0, t_ysum = 0.0, t_yprev_n = 0.0, t_ysum_n = 0.0, t_first_yaw = 0.0;
         const int32_t *t_seg_rows = nullptr;
         const double *t_coeffs = nullptr, *t_yaws = nullptr;
@@ -447,6 +447,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                             while (t_rin >= t_srows && t_seg + 1 < t_pm) { t_rin -= t_srows; ++t_seg; t_srows = t_seg_rows[t_seg]; }
                             coeffs_dma(t_coeffs + 24 * t_seg, tile2_lds);
                             seg_rows_issue(t_srows_nx, t_seg_rows + min(t_seg + 1, t_pm - 1));
+                            t_asked = 1;
                         }
                         if (!YAWSCAN && t_idx - t_ybase == 16) {
                             t_ybase = t_idx;
@@ -462,7 +463,13 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                     // hand-over the compute wave calls barrier j in the middle of tick j + 1, so this wave's iteration k runs
                     // between the middle of tick k + 1 and the middle of tick k + 2.
                     __builtin_amdgcn_s_setprio(0);
-                    if (t_phase == 1) { store_wave_loads_wait<kStoresPerTick>(t_srows_nx); t_eval_axis(0); }
+                    if (t_phase == 1) {
+                        // (only when some lane of the wave did ask for coefficients a tick ago -- 44 % of the outer ticks: the wait is
+                        // for the previous tick's STORES as well, and at two workgroups per CU those are not always down yet)
+                        if (__any(t_asked)) store_wave_loads_wait<kStoresPerTick>(t_srows_nx);
+                        t_asked = 0;
+                        t_eval_axis(0);
+                    }
                     else if (t_phase == 2) t_eval_axis(1);
                     else if (t_phase == 3) t_eval_axis(2);
                     else t_eval_yaw_and_hand_over();
