@@ -432,6 +432,10 @@ int uavac_pilot_tick(uavac_pilot *pilot, const uavac_vehicle *V, int what);
 #define UAVAC_PROBE_USE_MOMENT 1  /* (inner) allocation takes moment_in instead of body_rate's   */
 int uavac_probe_outer(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out);
 int uavac_probe_inner(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out);
+/* The sampler's heading of a velocity sample (csrc/minsnap_yaw.h: the device library's atan2 with the instruction count cut)
+ * beside the library's own atan2(y, x) on the same operands; DEVICE pointers, n values each, asynchronous.  They must agree bit
+ * for bit (np.arctan2 in MinimumSnap._calculate_yaws, minimum_snap.py:131, is matched to <= 1e-5 by either). */
+int uavac_probe_heading_dev(uavac_ctx *ctx, const double *y, const double *x, int64_t n, double *heading, double *library);
 
 /* ---------------------------------------------------------------------------------------------
  * RRT* planner -- replaces uav_ac/planning/rrt.py.

@@ -461,3 +461,53 @@ def test_dense_yaw_column_equals_the_rows_yaw(eng):
         assert torch.equal(plan.yaw, plan.traj[:, 9])
         # the missions' first headings: what the rows before the first usable heading hold, i.e. row 0's yaw
         assert torch.equal(plan.first_yaw, plan.traj[plan.row_offsets[:-1], 9])
+
+
+def test_sampler_heading_equals_the_device_library_atan2_bit_for_bit(eng):
+    """csrc/minsnap_yaw.h heading() is the device library's atan2 with the instruction count cut (three-source fmas instead of
+    fmac + a move per coefficient, no special-case tests): the same operations in the same order, so the same BITS -- over 2^24
+    random operand pairs of every magnitude and every pairing of special values (zeros of both signs, infinities, NaNs, denormals,
+    equal magnitudes, the axes)."""
+    import ctypes as C
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = 1 << 24
+    mant = torch.rand(2, n, generator=g, dtype=torch.float64) * 2 - 1
+    expo = torch.randint(-40, 40, (2, n), generator=g)
+    expo[:, : n // 4] = torch.randint(-1000, 1000, (2, n // 4), generator=g)         # a quarter over the whole exponent range
+    expo[:, n // 4: n // 2] = torch.randint(-3, 4, (2, n // 4), generator=g)         # a quarter at velocity-like magnitudes
+    v = torch.ldexp(mant, expo)
+    specials = torch.tensor([0.0, -0.0, 1.0, -1.0, float("inf"), float("-inf"), float("nan"), 5e-324, -5e-324, 2.2250738585072014e-308,
+                             1.7976931348623157e308, -1.7976931348623157e308, 1e-3, -1e-3, 3.0, -3.0, 0.5, 2.0 ** -600, 2.0 ** 600], dtype=torch.float64)
+    yy, xx = torch.meshgrid(specials, specials, indexing="ij")
+    y = torch.cat([v[0], yy.reshape(-1), v[0, :4096], v[0, :4096]]).to(eng.device)
+    x = torch.cat([v[1], xx.reshape(-1), v[0, :4096], -v[0, :4096]]).to(eng.device)
+    a, b = torch.empty_like(y), torch.empty_like(y)
+    eng.ctx.call("uavac_probe_heading_dev", y.data_ptr(), x.data_ptr(), C.c_int64(y.numel()), a.data_ptr(), b.data_ptr())
+    torch.cuda.synchronize()
+    same = (a.view(torch.int64) == b.view(torch.int64)) | (torch.isnan(a) & torch.isnan(b))
+    assert bool(same.all()), (y[~same][:4].tolist(), x[~same][:4].tolist(), a[~same][:4].tolist(), b[~same][:4].tolist())
+    ref = torch.atan2(y.cpu(), x.cpu())
+    ok = torch.isfinite(ref)
+    assert float((a.cpu()[ok] - ref[ok]).abs().max()) < 1e-14
+
+
+def test_heading_threshold_is_numpys_unfused_sum_of_squares(ctx):
+    """|v_xy| >= 1e-3 decides whether a row has a heading of its own (minimum_snap.py:128-129, np.linalg.norm = sqrt of a
+    rounded sum of rounded squares).  Velocities for which a fused multiply-add in vx^2 + vy^2 lands on the other side of the
+    threshold than NumPy's two rounded products (found by exact rational arithmetic): the row must take NumPy's side."""
+    from oracle.minsnap_oracle import yaws_from_velocity
+    pairs = [("0x1.c979106bbda29p-11", "0x1.001e375da1c15p-11"), ("0x1.11056ffcadd96p-11", "0x1.bf972ef14728bp-11"),
+             ("-0x1.f64a69e912dcfp-11", "0x1.2c8bc98d6f686p-12"), ("-0x1.ce85b735d7881p-11", "0x1.edc3e06b5604fp-12"),
+             ("-0x1.c40a0e4d6cf16p-11", "0x1.0997351d95b1bp-11"), ("0x1.7a6a13ec6710cp-11", "0x1.6ae0c76ec1f2cp-11"),
+             ("-0x1.f68ad299fcf30p-11", "0x1.2adbe40a08995p-12"), ("0x1.1556a9e8e62dep-11", "0x1.bceda915709e0p-11"),
+             ("-0x1.9b28de405ba7dp-11", "0x1.454efd7f47760p-11"), ("-0x1.2431c52b6b0dap-13", "0x1.03964ae034407p-10"),
+             ("-0x1.9b842123f91b6p-13", "0x1.010c2d80d11fbp-10"), ("0x1.ef32ec9f4beafp-11", "0x1.586affb58c88ep-12")]
+    rows = [[1.0, 0.25, 0.0]]
+    for i, (a, b) in enumerate(pairs):
+        rows += [[float.fromhex(a), float.fromhex(b), 0.1], [float.fromhex(b), float.fromhex(a), 0.0], [np.cos(0.4 * i), -np.sin(0.4 * i), 0.0]]
+    vel = np.array(rows)
+    h = np.sqrt(vel[:, 0] ** 2 + vel[:, 1] ** 2)
+    assert (h[1::3] < 1e-3).any() and (h[1::3] >= 1e-3).any()          # both sides of the threshold occur
+    got, want = _yaw_via_sampler(ctx, vel), yaws_from_velocity(vel)
+    assert np.allclose(got, want, rtol=0, atol=1e-12), np.flatnonzero(np.abs(got - want) > 1e-12)

@@ -5,6 +5,7 @@
 // run on the HIP path.  Records are array-of-structs; batches are small; not a hot path.
 
 #include "control_law.h"
+#include "minsnap_yaw.h"
 
 #include <cstring>
 #include <new>
@@ -158,9 +159,26 @@ int run_probe(uavac_ctx *ctx, const uavac_vehicle *V, Kern kern, const double *i
     return UAVAC_OK;
 }
 
+// the sampler's heading next to the device library's atan2 on the same operands (they must agree bit for bit)
+__global__ void probe_heading_kernel(const double *__restrict__ y, const double *__restrict__ x, long long n,
+                                     double *__restrict__ heading, double *__restrict__ library) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        heading[i] = uavac_yaw::heading(y[i], x[i]);
+        library[i] = atan2(y[i], x[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int uavac_probe_heading_dev(uavac_ctx *ctx, const double *y, const double *x, int64_t n, double *heading, double *library) {
+    UAVAC_ENTER(ctx);
+    if (n < 1 || !y || !x || !heading || !library) return uavac_fail(ctx, UAVAC_EINVAL, "bad n or null pointer");
+    hipLaunchKernelGGL(probe_heading_kernel, dim3(1024), dim3(256), 0, ctx->stream, y, x, (long long)n, heading, library);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
 
 int uavac_probe_outer(uavac_ctx *ctx, const uavac_vehicle *V, const double *in, int B, int mask, double *out) {
     return run_probe(ctx, V, probe_outer_kernel, in, UAVAC_PROBE_OUTER_IN, B, mask, out, UAVAC_PROBE_OUTER_OUT);

@@ -16,6 +16,13 @@
 #include "minsnap_eval.h"
 #include "minsnap_yaw.h"
 
+#ifdef UAVAC_DIAG_XCD_PERM      // DIAGNOSTIC builds only (tools/scratch/xcd_perm_probe.py): which eighth of the missions each XCD takes
+__device__ int g_diag_xcd_perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+extern "C" int uavac_diag_xcd_perm_one(const int *perm) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xcd_perm), perm, 8 * sizeof(int)) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace {
 
 constexpr int SB = 64;                  // rows per chunk == threads per workgroup == one wavefront
@@ -107,7 +114,13 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     double *ybuf = reinterpret_cast<double *>(pre + ((m + 2 + 1) & ~1));          // [kYawGroup * SB]
 
     const int lane = threadIdx.x;
+#if defined(UAVAC_DIAG_XCD_PERM)
+    const int b = xcd_contiguous((blockIdx.x & ~7) | g_diag_xcd_perm[blockIdx.x & 7], gridDim.x);
+#elif defined(UAVAC_DIAG_NO_XCD)
+    const int b = blockIdx.x;
+#else
     const int b = xcd_contiguous(blockIdx.x, gridDim.x);      // consecutive missions (consecutive rows in HBM) per XCD
+#endif
     const int64_t row0 = row_offsets[b];
     const int N = (int)(row_offsets[b + 1] - row0);
     if (capacity_rows >= 0 && row_offsets[B] > capacity_rows) {       // uniform over the launch: nobody writes
@@ -178,7 +191,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
             if (in) atomicOr(&hit[seg0 + s], 1);
         }
         const bool valid = active && has_heading(vx, vy);
-        const double ang = valid ? atan2(vy, vx) : 0.0;
+        const double ang = valid ? heading(vy, vx) : 0.0;
         bool first_here;
         double first_yaw;
         const double yaw = yaw_chunk(valid, ang, lane, carry, first_here, first_yaw);
@@ -266,7 +279,7 @@ __global__ void __launch_bounds__(SB) yaw_scan_kernel(const double *__restrict__
         const bool active = r < N;
         const double vx = active ? vel[(row0 + r) * 3] : 0.0, vy = active ? vel[(row0 + r) * 3 + 1] : 0.0;
         const bool valid = active && has_heading(vx, vy);
-        const double ang = valid ? atan2(vy, vx) : 0.0;
+        const double ang = valid ? heading(vy, vx) : 0.0;
         bool first_here;
         double first_yaw;
         const double yaw = yaw_chunk(valid, ang, lane, carry, first_here, first_yaw);

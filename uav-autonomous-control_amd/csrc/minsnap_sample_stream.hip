@@ -39,6 +39,13 @@ extern "C" int uavac_sampler_diag_read(long long *out, int n) {
 }
 #endif
 
+#ifdef UAVAC_DIAG_XCD_PERM      // DIAGNOSTIC builds only (tools/scratch/xcd_perm_probe.py): which eighth of the missions each XCD takes
+__device__ int g_diag_xcd_perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+extern "C" int uavac_diag_xcd_perm_stream(const int *perm) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xcd_perm), perm, 8 * sizeof(int)) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace {
 
 constexpr int kChunkRows = 64;
@@ -114,7 +121,13 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
         if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[2], 1);
         return;
     }
+#if defined(UAVAC_DIAG_XCD_PERM)
+    const int wg = xcd_contiguous((blockIdx.x & ~7) | g_diag_xcd_perm[blockIdx.x & 7], gridDim.x);
+#elif defined(UAVAC_DIAG_NO_XCD)
+    const int wg = blockIdx.x;
+#else
     const int wg = xcd_contiguous(blockIdx.x, gridDim.x);                   // consecutive missions (consecutive rows) per XCD
+#endif
     const int b0 = wg * G;
     const int Gn = min(G, B - b0);
 
@@ -175,13 +188,17 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
         const double *clj = cl + (size_t)j * 24 * m;
         const int *prej = pre + (size_t)j * mp;
         const int endv = (lane < mb) ? prej[lane + 1] : 0x7fffffff;       // lane s: first row past segment s
-        int i = item0 + ((w - item0) % W + W) % W;                        // first item >= item0 congruent to w
-        for (; i < item0 + nitems; i += W) {
+        // (the compiler keeps this loop's counter in a vector register -- it takes the loop for divergent -- and with it every
+        // address derived from it: the body works on copies made scalar by hand)
+        const int item0s = __builtin_amdgcn_readfirstlane(item0);
+        for (int iv = item0s + ((w - item0s) % W + W) % W; iv < item0s + nitems; iv += W) {   // first item >= item0 congruent to w, ...
+            const int i = __builtin_amdgcn_readfirstlane(iv);
 #ifdef UAVAC_DIAG_STAMPS
             const long long sd0 = SDIAG_NOW();
 #endif
-            const long long g0 = ((kfirst + (i - item0)) << 6) - phase;   // row (of the batch) in lane 0; may lie before the buffer
-            const int rel0 = (int)(g0 - Rj);                              // the same, counted from the mission's first row
+            // (made scalar by hand: the compiler takes them for per-lane values and does the write-out's address arithmetic in vector instructions)
+            const long long g0 = uniform64(((kfirst + (i - item0s)) << 6) - phase);   // row (of the batch) in lane 0; may lie before the buffer
+            const int rel0 = __builtin_amdgcn_readfirstlane((int)(g0 - Rj));         // the same, counted from the mission's first row
             const int r = rel0 + lane;
             const bool active = r >= 0 && r < Nj;
             // ---- the rows on their own: evaluated and staged at once (the yaw column follows when the history is known)
@@ -215,7 +232,11 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
                 }
             }
             const bool valid = active && has_heading(vx, vy);
-            const double ang = valid ? atan2(vy, vx) : 0.0;
+#ifdef UAVAC_DIAG_NO_ATAN
+            const double ang = valid ? vy + vx : 0.0;
+#else
+            const double ang = valid ? heading(vy, vx) : 0.0;
+#endif
             const unsigned long long mask = __ballot(valid);
             const unsigned long long below = (1ull << lane) - 1ull;
             const unsigned long long lower = mask & below;
@@ -245,7 +266,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
                     __builtin_amdgcn_s_sleep(1);
                     mail_poll(src, seq, has);
                 }
-                if (i > item0) {
+                if (i > item0s) {
                     double ca, cs, cf;
                     mail_read(src, ca, cs, cf);
                     c_has = __builtin_amdgcn_readfirstlane(has) != 0;
@@ -280,24 +301,36 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
             if (first_here && rel0 > 0) {                                   // rows of this mission in earlier chunks wait for this heading
                 if (lane == 0) { patch_yaw[j] = first_ang; patch_rows[j] = rel0; }
             }
-            if (i == item0 + nitems - 1 && first_yaw_out && lane == 0) first_yaw_out[b0 + j] = m_first;
+            if (i == item0s + nitems - 1 && first_yaw_out && lane == 0) first_yaw_out[b0 + j] = m_first;
             if (active) {
                 if (yaw_dense) yaw_dense[g0 + lane] = yaw;
                 stage[lane * UAVAC_TRAJ_COLS + 9] = yaw;
             }
             lds_wave_fence();
             // ---- write-out: the item's doubles [e0, e1) of the chunk, 16-byte stores from even elements, whole lines
-            const int l0 = rel0 < 0 ? -rel0 : 0, l1 = Nj - rel0 < 64 ? Nj - rel0 : 64;
-            const int e0 = l0 * UAVAC_TRAJ_COLS, e1 = l1 * UAVAC_TRAJ_COLS;
             double *dst = traj + g0 * UAVAC_TRAJ_COLS;                      // 128-byte aligned (never dereferenced before e0)
-            if ((e0 & 1) && lane == 0) dst[e0] = stage[e0];
-            if ((e1 & 1) && lane == 63) dst[e1 - 1] = stage[e1 - 1];
-            const int p0 = (e0 + 1) >> 1, p1 = e1 >> 1;
-            for (int p = p0 + lane; p < p1; p += 64) {
-                double2 v;
-                v.x = stage[2 * p];
-                v.y = stage[2 * p + 1];
-                *reinterpret_cast<double2 *>(dst + 2 * p) = v;
+            if (rel0 >= 0 && rel0 + 64 <= Nj) {
+                // a whole chunk (all but a mission's first and last item): 5 1/2 stores of 1 KB, scalar base + lane offset + immediate
+                // (the second base keeps every immediate below 4 KB: beyond that the compiler falls back to per-lane 64-bit addresses)
+                const double2 *sp = reinterpret_cast<const double2 *>(stage) + lane;
+                double *dst2 = dst + 512;
+                asm("" : "+s"(dst2));                                        // (opaque: otherwise folded back into dst + 4096)
+                double2 *dp = reinterpret_cast<double2 *>(dst) + lane, *dq = reinterpret_cast<double2 *>(dst2) + lane;
+                double2 v0 = sp[0], v1 = sp[64], v2 = sp[128], v3 = sp[192], v4 = sp[256];
+                dp[0] = v0; dp[64] = v1; dp[128] = v2; dp[192] = v3; dq[0] = v4;
+                if (lane < 32) dq[64] = sp[320];
+            } else {
+                const int l0 = rel0 < 0 ? -rel0 : 0, l1 = Nj - rel0 < 64 ? Nj - rel0 : 64;
+                const int e0 = l0 * UAVAC_TRAJ_COLS, e1 = l1 * UAVAC_TRAJ_COLS;
+                if ((e0 & 1) && lane == 0) dst[e0] = stage[e0];
+                if ((e1 & 1) && lane == 63) dst[e1 - 1] = stage[e1 - 1];
+                const int p0 = (e0 + 1) >> 1, p1 = e1 >> 1;
+                for (int p = p0 + lane; p < p1; p += 64) {
+                    double2 v;
+                    v.x = stage[2 * p];
+                    v.y = stage[2 * p + 1];
+                    *reinterpret_cast<double2 *>(dst + 2 * p) = v;
+                }
             }
             lds_wave_fence();                     // the staged chunk is in registers / on its way; its stores stay in flight
 #ifdef UAVAC_DIAG_STAMPS

@@ -114,6 +114,7 @@ _SIGNATURES = {
     "uavac_pilot_tick": (C.c_int, [_P, C.POINTER(Vehicle), C.c_int]),
     "uavac_probe_outer": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
     "uavac_probe_inner": (C.c_int, [_P, C.POINTER(Vehicle), _P, C.c_int, C.c_int, _P]),
+    "uavac_probe_heading_dev": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
     "uavac_rrt_star_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 7),
     "uavac_rrt_star": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.c_int] + [_P] * 7),
     "uavac_rrt_segment_hits_dev": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P]),
