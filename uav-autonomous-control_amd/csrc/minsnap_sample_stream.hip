@@ -78,8 +78,9 @@ __device__ __forceinline__ unsigned lds_address(const void *p) { return (unsigne
 __device__ __forceinline__ void mail_poll(unsigned a, int &seq, int &has) {
     long long v;
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
-    seq = (int)(v & 0xffffffffll);
-    has = (int)(v >> 32);
+    // wave-uniform, and said so: with per-lane values the compiler builds the poll loop out of exec masks (unrolled six times)
+    seq = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    has = __builtin_amdgcn_readfirstlane((int)(v >> 32));
 }
 __device__ __forceinline__ void mail_read(unsigned a, double &ang, double &sum, double &first) {
     asm volatile("ds_read_b64 %0, %3 offset:8\n\tds_read_b64 %1, %3 offset:16\n\tds_read_b64 %2, %3 offset:24\n\ts_waitcnt lgkmcnt(0)"
@@ -247,6 +248,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
             const double first_ang = lane_value(ang, first_lane);
             const double last_ang = lane_value(ang, mask ? 63 - __clzll((long long)mask) : 0);
 
+            const unsigned long long wraps_own = __ballot(corr != 0.0);    // corrections inside the item (known before the carry)
             // ---- the carry: wait for the item before (ordering of the mailboxes; its values only inside a mission)
             bool c_has = false;
             double c_ang = 0.0, c_sum = 0.0, c_first = 0.0;
@@ -277,15 +279,19 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
             const long long sd2 = SDIAG_NOW();
 #endif
             // np.unwrap's step from the last heading before this item to its first one, then np.cumsum's order, left to right
+            // (an item without corrections -- nearly every one -- hands the sum on as it came: the test is all that stands between
+            // the carry's arrival and its publication)
             const double cb = (mask != 0ull && c_has) ? unwrap_correction(first_ang - c_ang) : 0.0;
-            if (lane == first_lane && valid) corr = cb;                     // (0 unless c_has: that lane has no predecessor)
-            unsigned long long wraps = __ballot(corr != 0.0);
             double cum = c_sum, run = c_sum;
-            while (wraps != 0ull) {
-                const int l = __builtin_ctzll(wraps);
-                wraps &= wraps - 1ull;
-                run = run + lane_value(corr, l);
-                if (lane >= l) cum = run;
+            if (wraps_own != 0ull || __ballot(cb != 0.0) != 0ull) {
+                if (lane == first_lane && valid) corr = cb;                 // (0 unless c_has: that lane has no predecessor)
+                unsigned long long wraps = __ballot(corr != 0.0);
+                while (wraps != 0ull) {
+                    const int l = __builtin_ctzll(wraps);
+                    wraps &= wraps - 1ull;
+                    run = run + lane_value(corr, l);
+                    if (lane >= l) cum = run;
+                }
             }
             const bool first_here = !c_has && mask != 0ull;
             const double m_first = c_has ? c_first : (mask != 0ull ? first_ang : 0.0);
