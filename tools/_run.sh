@@ -1,1 +1,2 @@
-timeout 300 python tools/sampler_stream_ab.py 8 65536 12 1x1,4x1,3x1,2x1,3x2 2>/dev/null | grep waves_x
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
+python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_now.json

@@ -97,7 +97,7 @@ __device__ __forceinline__ int padded_pre(int m) { return (m + 2 + 1) & ~1; }
 // HITS / DERIVS / RAGGED as in minsnap_sample.hip.  G = missions per workgroup; phase = rows by which the 64-row grid is
 // shifted so that chunk starts are 128-byte aligned in `traj` (0 .. 63, from the buffer's address).
 template <int W, bool HITS, bool DERIVS, bool RAGGED>
-__global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_sample_stream_kernel(
+__global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_sample_stream_kernel(
     const double *__restrict__ coeffs, const int32_t *__restrict__ seg_rows, const int64_t *__restrict__ row_offsets, int B,
     int m, double dt, double *__restrict__ traj, const double *__restrict__ aabb, int32_t *__restrict__ hit,
     double *__restrict__ yaw_dense, double *__restrict__ jerk, double *__restrict__ snap, int64_t capacity_rows,
@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
     // the mailboxes are a STATIC LDS array: volatile accesses through a pointer derived from the dynamic array stay generic
     // (flat) loads and stores, and a flat access waits for the wave's global stores as well (s_waitcnt vmcnt(0) on every poll)
     __shared__ Mail mail[W];
+    __shared__ __attribute__((aligned(16))) double heading_poly[kHeadingCoefficients];      // see HeadingFromLds
     int *patch_rows = segn + G;                                             // [G] how many leading rows to patch (0: none)
 
     if (capacity_rows >= 0 && row_offsets[B] > capacity_rows) {             // uniform over the launch: nobody writes
@@ -135,6 +136,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
     // ---- tables of this workgroup's missions
     if (tid <= Gn) rowoff[tid] = row_offsets[b0 + tid];
     if (tid < W) { mail[tid].seq = 0; }
+    if (tid < kHeadingCoefficients) heading_poly[tid] = kHeadingPoly[tid];
     for (int j = 0; j < Gn; ++j) {
         long long sb = (long long)(b0 + j) * m;                             // uniform: scalar loads
         int mb = m;
@@ -236,7 +238,12 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 5)) minsnap_s
 #ifdef UAVAC_DIAG_NO_ATAN
             const double ang = valid ? vy + vx : 0.0;
 #else
-            const double ang = valid ? heading(vy, vx) : 0.0;
+            double ang = 0.0;
+            if (valid) {
+                HeadingFromLds hc;
+                hc.lds = lds_address(heading_poly);
+                ang = heading_with(vy, vx, hc);
+            }
 #endif
             const unsigned long long mask = __ballot(valid);
             const unsigned long long below = (1ull << lane) - 1ull;
