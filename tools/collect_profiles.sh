@@ -43,7 +43,7 @@ timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-form
 python3 tools/rollout_clock.py --report "$OUT/pmc_rclock" > "$OUT/${TAG}_rollout_clock.jsonl" 2>/dev/null
 python3 tools/replan_rate.py 4096 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_replan_rate.txt"
 # 8. round 4: the two sampler kernels on six row buffers side by side; plan-fed against row-fed rollout by batch size
-python3 tools/sampler_stream_ab.py 6 65536 12 1x1,4x1,2x1,8x1,4x2 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_sampler_stream_ab.jsonl"
+python3 tools/sampler_stream_ab.py 8 65536 12 1x1,4x1,2x1,8x1,4x2 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_sampler_stream_ab.jsonl"
 python3 tools/plan_vs_rows.py 2>/dev/null | grep "B=" > "$OUT/${TAG}_plan_vs_rows.txt"
 rm -rf "$OUT/trace/"*results.db "$OUT/pmc_small" "$OUT/pmc_rclock"
 ls -la "$OUT"
