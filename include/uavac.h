@@ -123,7 +123,10 @@ const char *uavac_build_info(void);
  * wave evaluates target rows and reloads a segment's coefficients through registers on the spot; 1 the same with the
  * coefficients arriving by LDS-DMA an outer tick ahead; 2 the second (store) wave owns the cursor and evaluates the rows in
  * its idle time (kernels that have one; inner_per_outer >= 7).  Same bits in every mode.  "solve_park": -1 (default: chosen per launch), 0, 1 = the coefficient solve parks its forward sweep in the HBM
- * workspace / in LDS (when (m - 1) x 14 KB fit; same bits).  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
+ * workspace / in LDS (when (m - 1) x 14 KB fit; same bits); "solve_lanes": -1 (default: chosen per launch), 64, 32, 16 = lanes
+ * of a wavefront of the solve that carry a mission (fewer = more wavefronts for the same batch; same bits); "solve_keep": -1
+ * (default: chosen per launch), 0, 1 = the solve of a uniform batch keeps the first five knots' blocks of its forward sweep in
+ * registers instead of the workspace (same bits).  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
  * chunk-streaming sampler, "sampler_group": 1 (default) .. 64 = consecutive missions per workgroup;
  * "sampler_waves" 1 = the one-wave-per-mission sampler (same rows bit for bit; faster into some row
  * buffers, slower into most: DESIGN K2).

@@ -64,6 +64,35 @@ def test_solve_parked_in_lds_equals_solve_parked_in_hbm(eng, m):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("m", [1, 2, 3, 6, 7, 12, 20])
+def test_solve_launch_shapes_give_the_same_coefficients_bit_for_bit(eng, m):
+    """Options "solve_lanes" (64 / 32 / 16 lanes of a wave carry a mission: more waves for the same batch) and "solve_keep" (the
+    first five knots' blocks of the forward sweep stay in registers instead of the workspace) choose how the solve is launched,
+    never what it computes: uniform and ragged batches, sizes that are no multiple of 64, 32 or 16 lanes, fewer and more knots
+    than the five that are kept."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(333, m)
+    ragged = [w[: 2 + (i % m)] for i, w in enumerate(wps)]
+    got = {}
+    try:
+        eng.ctx.set_option("solve_park", 0)
+        for lanes, keep in ((64, 0), (32, 0), (16, 0), (64, 1), (-1, -1)):
+            eng.ctx.set_option("solve_lanes", lanes)
+            eng.ctx.set_option("solve_keep", keep)
+            plan = eng.plan(wps, 3.0, 0.01)
+            rb = eng.plan_ragged(ragged, 3.0, 0.01)
+            assert torch.isfinite(plan.coeffs).all()
+            got[(lanes, keep)] = (plan.coeffs.clone(), plan.traj.clone(), rb.coeffs.clone(), rb.traj.clone())
+    finally:
+        eng.ctx.set_option("solve_park", -1)
+        eng.ctx.set_option("solve_lanes", -1)
+        eng.ctx.set_option("solve_keep", -1)
+    for k, v in got.items():
+        for x, y in zip(got[(64, 0)], v):
+            assert torch.equal(x, y), k
+
+
 @pytest.mark.parametrize("B", [3, 9, 40])
 def test_host_twins_move_one_piece_several_pieces_and_more_than_a_megabyte(ctx, eng, B):
     """The host-pointer twins stage pageable buffers through a pinned ping-pong buffer in 256 KiB pieces (two in flight) up to

@@ -177,9 +177,10 @@ constexpr int TB = 64;          // lanes (missions) per workgroup = one wave
 // waypoints, times and coefficients of the batch lie back to back.  Lanes then run different numbers of knots; the backward
 // sweep counts segments from each mission's own end (lane l handles segment m_l - 1 - i in step i), so that the 64 x 24
 // transpose still moves one segment of every mission that has one left.
+// NREG: [Ut | rt] of the first NREG knots stay in registers (uniform batches; see `kept`).
 // PARK_LDS: the forward sweep parks [Ut | rt] in the wave's own LDS ([m - 1][28][64] doubles, dynamic) instead of the HBM
 // workspace -- when it fits (m <= 8 at 100 KB per wave) and the batch is small enough for that to pay (see the launcher).
-template <bool RAGGED, bool PARK_LDS = false>
+template <bool RAGGED, bool PARK_LDS = false, int NACT = TB, int NREG = 0>
 __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__restrict__ wp,
                                                              const double *__restrict__ times, int B, int m_uniform,
                                                              double *__restrict__ ws, double *__restrict__ coeffs,
@@ -194,23 +195,26 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     // obstacle loop (uavac_minsnap_obstacle_round_dev): only the missions still being corrected are re-solved -- a wave none
     // of whose missions is active leaves at once (the others solve all 64: their coefficients are simply the same as before)
     if (active) {
-        const int b_ = blockIdx.x * TB + threadIdx.x;
-        if (!__any(b_ < B && active[b_] != 0)) return;
+        const int b_ = blockIdx.x * NACT + threadIdx.x;
+        if (!__any((int)threadIdx.x < NACT && b_ < B && active[b_] != 0)) return;
     }
     __shared__ double stage[TB * 25];                 // one segment's 24 coefficients per mission (+1 pad)
-    extern __shared__ double park_lds[];              // PARK_LDS: [m_uniform - 1][28][64]
+    extern __shared__ double park_lds[];              // PARK_LDS: [m_uniform - 1][28][NACT]
     __shared__ int64_t seg0_of[RAGGED ? TB : 1];      // ragged: first segment and segment count of every mission of the wave
     __shared__ int m_of[RAGGED ? TB : 1];
+    // NACT < 64: only the first NACT lanes carry a mission -- twice (four times) the waves for the same batch.  The kernel is
+    // bound by the latency of its dependent chains at one wave per SIMD (B = 65 536: 1 024 waves), not by issue: two half-full
+    // waves per SIMD hide each other's latencies (the launcher picks; option "solve_lanes")
     const int lane = threadIdx.x;
-    const int b0 = blockIdx.x * TB;
+    const int b0 = blockIdx.x * NACT;
     const int b = b0 + lane;
-    const bool live = b < B;
+    const bool live = lane < NACT && b < B;
     const int bb = live ? b : B - 1;
     const size_t sB = (size_t)B;
     // where knot k's parked block lives and how far apart its 28 values are
-    const size_t pst = PARK_LDS ? (size_t)TB : sB;
+    const size_t pst = PARK_LDS ? (size_t)NACT : sB;
     auto park_at = [&](int k_) -> double * {
-        return PARK_LDS ? park_lds + (size_t)k_ * 28 * TB + threadIdx.x : ws + ((size_t)k_ * 28) * sB + (b0 + (int)threadIdx.x < B ? b0 + (int)threadIdx.x : B - 1);
+        return PARK_LDS ? park_lds + (size_t)k_ * 28 * NACT + (threadIdx.x < NACT ? threadIdx.x : 0) : ws + ((size_t)k_ * 28) * sB + bb;
     };
     int m = m_uniform;
     const double *w = wp + (size_t)bb * (m_uniform + 1) * 3;
@@ -223,13 +227,16 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
         tm = times + (size_t)s0;
         seg0_of[lane] = s0;
         m_of[lane] = m;
-        m_top = m;
+        m_top = live ? m : 1;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m_top = max(m_top, __shfl_xor(m_top, d));
         lds_wave_fence();
     }
     const int nk = m - 1;
     bool ok = true;
+    // NREG > 0 (uniform batches): [Ut | rt] of the first NREG knots stay in the lane's registers (the compiler places them in
+    // the accumulation half of the register file: one wave per SIMD has 512 registers per lane) instead of the HBM workspace
+    double kept[NREG > 0 ? NREG : 1][28];
 
     // ------------------------------------------------------------------ forward sweep over interior knots
     {
@@ -284,12 +291,26 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
             }
             ok = solve4(S, R) && ok;
             double *o = park_at(kk);
+            const bool in_regs = NREG > 0 && kk < NREG;      // (uniform: every lane of a uniform batch is at the same knot)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (PARK_LDS || live) o[(size_t)(i * 4 + j) * pst] = R[i][j]; }
+                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (!in_regs && (PARK_LDS ? lane < NACT : live)) o[(size_t)(i * 4 + j) * pst] = R[i][j]; }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (PARK_LDS || live) o[(size_t)(16 + i * 3 + a) * pst] = R[i][4 + a]; }
+                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (!in_regs && (PARK_LDS ? lane < NACT : live)) o[(size_t)(16 + i * 3 + a) * pst] = R[i][4 + a]; }
+            }
+            if (in_regs) {
+#pragma unroll
+                for (int q = 0; q < NREG; ++q)
+                    if (kk == q) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) kept[q][i * 4 + j] = R[i][j];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) kept[q][16 + i * 3 + a] = R[i][4 + a];
+                        }
+                    }
             }
             prev = cur;
         }
@@ -309,7 +330,7 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     // 64 missions x 24 doubles of one step leave the stage as 192-byte runs: mission q's segment sq = m_q - 1 - step, at
     // coeffs[(first segment of q + sq) * 24]
     auto flush = [&](int step) {
-        for (int e = lane; e < TB * 24; e += TB) {
+        for (int e = lane; e < NACT * 24; e += TB) {
             const int q = e / 24, j = e - q * 24;
             const int sq = (RAGGED ? m_of[q] : m_uniform) - 1 - step;
             const size_t first = RAGGED ? (size_t)seg0_of[q] : (size_t)(b0 + q) * m_uniform;
@@ -321,8 +342,17 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     {
         const double *o = park_at(nk >= 1 ? nk - 1 : 0);
         if (nk >= 1) {
+            if (NREG > 0 && nk - 1 < NREG) {
 #pragma unroll
-            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
+                for (int q = 0; q < NREG; ++q)
+                    if (nk - 1 == q) {
+#pragma unroll
+                        for (int i = 0; i < 28; ++i) nxt[i] = kept[q][i];
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
+            }
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) nw[a] = w[3 * (m - 1) + a];
@@ -338,9 +368,18 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
         const double p0[3] = {nw[0], nw[1], nw[2]};
         if (step > 0) flush(step - 1);                  // reads the stage before this step overwrites it (LDS is in order)
         if (s >= 2) {
-            const double *o = park_at(s - 2);
+            if (NREG > 0 && s - 2 < NREG) {
 #pragma unroll
-            for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
+                for (int q = 0; q < NREG; ++q)
+                    if (s - 2 == q) {
+#pragma unroll
+                        for (int i = 0; i < 28; ++i) nxt[i] = kept[q][i];
+                    }
+            } else {
+                const double *o = park_at(s - 2);
+#pragma unroll
+                for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
+            }
         }
         if (s >= 1) {
 #pragma unroll
@@ -405,34 +444,42 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
         UAVAC_HIP(ctx, hipMalloc(&ctx->d_ws, sizeof(double) * need));
         ctx->ws_cap = need;
     }
-    // Parking in LDS (north_star's "LDS-staged" solve): (m - 1) * 14 336 bytes per wave, so m <= 11 fits the CU's 160 KB at all and
-    // a CU holds floor(144 KB / that) waves at a time instead of the four the HBM-parked kernel runs (one per SIMD) -- with more
-    // waves than that the launch goes round after round.  Measured (tools/solve_time.py, profiles/r04_solve_park.txt); the
-    // launcher takes LDS where that was faster: the whole batch resident at once.  Option "solve_park": -1 auto, 0 HBM, 1 LDS.
-    const size_t park = (size_t)(m > 1 ? m - 1 : 0) * 28 * TB * sizeof(double);
+    // How the solve is launched (never what it computes: tests/test_gpu_planner.py compares the coefficients bit for bit).
+    //  * lanes: 64, 32 or 16 lanes of a wave carry a mission.  Below a chip's worth of full waves the kernel is bound by the
+    //    latency of its dependent chains at one wave per SIMD, and two half-full waves hide each other's (B = 32 768, m = 8:
+    //    53 -> 49 us; B = 4 096: 45 -> 37 us).  Option "solve_lanes".
+    //  * parking in LDS (north_star's "LDS-staged" solve): (m - 1) x 28 x lanes doubles per wave instead of the HBM workspace, when
+    //    that fits and every wave of the launch is resident at once (a CU holds floor(156 KB / that) of them).  Option "solve_park".
+    //  * from a chip's worth of full waves on, the bound is the workspace's traffic (0.71 GB per launch at B = 65 536, m = 12
+    //    against 0.18 GB of inputs and coefficients): the first five knots' blocks stay in registers (146 -> 115 us there,
+    //    394 -> 278 us at B = 262 144, m = 8).  Uniform batches; option "solve_keep".
+    const int waves64 = (B + TB - 1) / TB, cus = ctx->n_simds / 4;
+    int lanes = ctx->solve_lanes;
+    if (lanes != 64 && lanes != 32 && lanes != 16) lanes = waves64 <= ctx->n_simds ? 32 : 64;
+    const int waves = (B + lanes - 1) / lanes;
+    const size_t park = (size_t)(m > 1 ? m - 1 : 0) * 28 * lanes * sizeof(double);
     const size_t static_lds = sizeof(double) * TB * 25 + (seg_offsets ? TB * 12 : 12);
     const bool fits = m > 1 && park + static_lds <= (size_t)150 * 1024;
-    const int waves = (B + TB - 1) / TB, cus = ctx->n_simds / 4;
     const int per_cu = fits ? (int)(((size_t)156 * 1024) / (park + static_lds)) : 0;
-    const bool lds_park = fits && (ctx->solve_park >= 0 ? ctx->solve_park != 0 : waves <= cus * (per_cu < 4 ? per_cu : 4));
-    if (lds_park) {
-        if (seg_offsets) {
-            auto kern = minsnap_solve_bt_kernel<true, true>;
-            if (park > 48 * 1024) UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)park));
-            hipLaunchKernelGGL(kern, dim3(waves), dim3(TB), park, ctx->stream, wp, times, B, m, ctx->d_ws, coeffs, status, ctx->d_flags,
-                               seg_offsets, guard_rows, guard_capacity, active);
-        } else {
-            auto kern = minsnap_solve_bt_kernel<false, true>;
-            if (park > 48 * 1024) UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)park));
-            hipLaunchKernelGGL(kern, dim3(waves), dim3(TB), park, ctx->stream, wp, times, B, m, ctx->d_ws, coeffs, status, ctx->d_flags,
-                               seg_offsets, guard_rows, guard_capacity, active);
-        }
-    } else if (seg_offsets)
-        hipLaunchKernelGGL(minsnap_solve_bt_kernel<true>, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
-                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets, guard_rows, guard_capacity, active);
-    else
-        hipLaunchKernelGGL(minsnap_solve_bt_kernel<false>, dim3((B + TB - 1) / TB), dim3(TB), 0, ctx->stream, wp, times, B, m,
-                           ctx->d_ws, coeffs, status, ctx->d_flags, seg_offsets, guard_rows, guard_capacity, active);
+    const bool lds_park = fits && (ctx->solve_park >= 0 ? ctx->solve_park != 0 : waves <= cus * (per_cu < 8 ? per_cu : 8));
+    const bool keep = !seg_offsets && !lds_park && (ctx->solve_keep >= 0 ? ctx->solve_keep != 0 : (ctx->solve_lanes < 0 && waves64 >= ctx->n_simds));
+    const dim3 grid(keep ? waves64 : waves);
+#define UAVAC_SOLVE_LAUNCH(R, P, N, K)                                                                                             \
+    do {                                                                                                                            \
+        auto kern = minsnap_solve_bt_kernel<R, P, N, K>;                                                                            \
+        if (P && park > 48 * 1024) UAVAC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)park)); \
+        hipLaunchKernelGGL(kern, grid, dim3(TB), P ? park : 0, ctx->stream, wp, times, B, m, ctx->d_ws, coeffs, status, ctx->d_flags,   \
+                           seg_offsets, guard_rows, guard_capacity, active);                                                        \
+    } while (0)
+#define UAVAC_SOLVE_LANES(R, P)                                                                                                     \
+    do {                                                                                                                            \
+        if (lanes == 64) UAVAC_SOLVE_LAUNCH(R, P, 64, 0); else if (lanes == 32) UAVAC_SOLVE_LAUNCH(R, P, 32, 0); else UAVAC_SOLVE_LAUNCH(R, P, 16, 0); \
+    } while (0)
+    if (keep) UAVAC_SOLVE_LAUNCH(false, false, 64, 5);
+    else if (lds_park) { if (seg_offsets) UAVAC_SOLVE_LANES(true, true); else UAVAC_SOLVE_LANES(false, true); }
+    else { if (seg_offsets) UAVAC_SOLVE_LANES(true, false); else UAVAC_SOLVE_LANES(false, false); }
+#undef UAVAC_SOLVE_LANES
+#undef UAVAC_SOLVE_LAUNCH
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

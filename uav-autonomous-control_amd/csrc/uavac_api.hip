@@ -311,6 +311,11 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
         ctx->late_handover = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "solve_park") {
         ctx->solve_park = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "solve_keep") {
+        ctx->solve_keep = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "solve_lanes") {
+        if (value != -1 && value != 64 && value != 32 && value != 16) return uavac_fail(ctx, UAVAC_EINVAL, "solve_lanes is -1, 64, 32 or 16");
+        ctx->solve_lanes = value;
     } else if (n == "coeff_dma") {
         ctx->coeff_dma = value < 0 ? -1 : (value > 2 ? 2 : value);
     } else if (n == "idle_waves") {

@@ -37,6 +37,8 @@ struct uavac_ctx {
     int late_handover = -1;          // tuning: -1 = the launcher picks per launch; 0 / 1 = slab handed over at the end of the tick / a third of a tick later
     int coeff_dma = -1;              // tuning: -1 = the launcher picks per launch; 0 / 1 / 2 = the plan-fed rollout's PMODE (control_rollout.hip)
     int solve_park = -1;             // tuning: where the block-Thomas solve parks its forward sweep: -1 = the launcher picks, 0 = HBM workspace, 1 = LDS (when it fits)
+    int solve_lanes = -1;            // tuning: lanes per wave of the block-Thomas solve that carry a mission (64 / 32 / 16; -1 = the launcher picks)
+    int solve_keep = -1;             // tuning: the solve of a uniform batch keeps its first five knots' parked blocks in registers: -1 = the launcher picks, 0 / 1
     int idle_waves = -1;             // tuning: placeholder wave between compute and store wave (0 / 1); -1 = the launcher picks
     int lds_pad = 0;                 // tuning: extra dynamic LDS per rollout workgroup (bytes): caps the workgroups a CU takes
     int64_t log_pitch = 0;           // doubles per row of the rollout's logs; 0 = B (option "log_pitch")
