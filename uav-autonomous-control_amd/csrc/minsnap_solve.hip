@@ -103,6 +103,9 @@ __global__ void __launch_bounds__(256) row_counts_kernel(const double *__restric
         seg_rows += seg0;
         double x0 = w[0], y0 = w[1], z0 = w[2];
         bad = bad || !(isfinite(x0) && isfinite(y0) && isfinite(z0));
+        // (one wave per SIMD at B = 65 536 and a square root and two divisions per segment, each a chain of dependent Newton
+        // steps: four segments side by side fill the gaps)
+#pragma unroll 4
         for (int s = 0; s < m; ++s) {
             double x1 = w[3 * s + 3], y1 = w[3 * s + 4], z1 = w[3 * s + 5];
             double dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
