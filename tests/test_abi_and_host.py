@@ -139,3 +139,16 @@ def test_rollout_kernels_keep_two_waves_per_simd():
     assert len(counts) >= 40 and max(v for _, v, _ in counts) <= 256 and all(s == 0 for _, _, s in counts)
     info = nat.lib().uavac_build_info().decode()
     assert info.startswith("libuavac %d; gfx950; HIP " % nat.VERSION) and "clang" in info.lower(), info
+
+
+def test_planning_kernels_keep_their_register_budgets():
+    """The streaming sampler at six waves per SIMD (<= 80 VGPRs; four with jerk / snap), the solve at two (one for the variant that
+    keeps five knots in registers), none with spills: the second check of __graft_entry__.build()."""
+    from uav_ac import _buildcheck
+    from uav_ac import _native as nat
+    nat.lib()
+    counts = _buildcheck.check_planning_registers()
+    if counts is None:
+        pytest.skip("no build directory / LLVM tools: library was built elsewhere")
+    assert len(counts) >= 28 and all(s == 0 for _, _, s in counts)
+    assert any(v > 256 for n, v, _ in counts if "minsnap_solve_bt_kernel" in n)          # the five-knot variant really uses the whole file
