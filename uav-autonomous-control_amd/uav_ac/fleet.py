@@ -46,6 +46,7 @@ class Plan:
     yaw: "object" = None     # (N,) f64 or None: the yaw column on its own (== traj[:, 9]); one way to feed the plan-fed rollout
     first_yaw: "object" = None   # (B,) f64: heading of each mission's first row that has one; lets the rollout scan the yaw itself
     placement_ms: "object" = None    # sampler times of the candidate row buffers when plan(..., placement_trials > 1) chose one
+    pooled: bool = False             # the rows live in the Engine's pooled buffer (shared with every other pooled plan of that Engine)
     epoch: int = 0                   # bumped whenever the plan is re-solved / re-sampled in place (Engine.replan / solve / sample):
                                      # an attached Fleet then rebuilds the yaw scan it carries instead of trusting a stale one
 
@@ -168,6 +169,7 @@ class Engine:
         self.ctx = nat.Context(self.device.index)
         self._torch = torch
         self._comm = None
+        self._row_pool = None            # plan(..., pool=True): the one pooled row buffer (rows x 11, float64)
 
     # -- plumbing ---------------------------------------------------------------
     def _bind_stream(self):
@@ -181,17 +183,20 @@ class Engine:
 
     # -- planning ---------------------------------------------------------------
     def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True, dense_yaw: bool = False,
-             placement_trials: int = 1) -> Plan:
+             placement_trials: int = 1, pool: bool = False) -> Plan:
         """Batched `MinimumSnap(path, None, velocity, dt).get_trajectory()` (minimum_snap.py:59-61,97-124).
         `strict`: raise UavacError(ESINGULAR) when a mission's knot system is singular (a repeated waypoint) instead of
         returning NaN coefficients for it; with strict=False inspect `plan.status`.
         `dense_yaw`: also keep the yaw column on its own (`plan.yaw`, 8 B per row).  Not needed to fly the plan: the
         plan-fed rollout scans the yaw itself from `plan.first_yaw` (8 B per mission).
-        `placement_trials` > 1 (opt-in; default 1 = take the first allocation): time the sampler on up to that many
-        candidate row buffers and keep the fastest (`place_rows`).  Only the one-wave-per-mission sampler
-        (`ctx.set_option("sampler_waves", 1)`) cares where its row buffer lies (1.25-1.33 ms into some allocations, 1.47-1.50
-        into others for the bench's 7.5 GB of rows); the default chunk-streaming sampler takes 1.34-1.40 ms into any of them
-        (DESIGN K2), so the default is no search."""
+        `placement_trials` > 1 (opt-in; default 1 = take the first allocation): draw up to that many row buffers one after the
+        other and keep the first of the fast kind, else the fastest seen (`place_rows`: at most TWO alive at any time).  Row
+        buffers come in three kinds (DESIGN K2, NOTES R4-6): the bench's 7.5 GB of rows take the default chunk-streaming sampler
+        1.24-1.26 ms into a fast one, 1.38-1.43 into a slow one, and a process's first large allocation is usually a slow one.
+        `pool=True`: the row buffer comes from / goes to the Engine's pool -- ONE buffer, found once (with `placement_trials`), handed
+        to every later pooled plan of at most that many rows, so that the search is paid once per process.  Pooled plans share
+        their rows' storage: one of them is current at a time (the use it is meant for: the same fleet planned again and again).
+        """
         torch = self._torch
         wp = self._dev(waypoints, torch.float64)
         if wp.dim() != 3 or wp.shape[2] != 3 or wp.shape[1] < 2:
@@ -210,13 +215,17 @@ class Engine:
                       _ptr(seg_rows), _ptr(row_offsets))
         self.ctx.call("uavac_minsnap_solve_dev", _ptr(wp), _ptr(times), B, m, _ptr(coeffs), _ptr(status))
         total = int(row_offsets[-1].item())                 # the one host sync: sizes the trajectory buffer
-        traj = torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
+        pooled = pool and self._row_pool is not None and self._row_pool.shape[0] >= total
+        traj = self._row_pool[:total] if pooled else torch.empty((total, nat.TRAJ_COLS), dtype=torch.float64, **kw)
         yaw = torch.empty((total,), dtype=torch.float64, **kw) if dense_yaw else None
         first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
         plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw, first_yaw)
         self.sample(plan)
-        if int(placement_trials) > 1 and total > 0:
+        if int(placement_trials) > 1 and total > 0 and not pooled:
             self.place_rows(plan, int(placement_trials))
+        if pool and not pooled:
+            self._row_pool = plan.traj                           # (a larger pooled plan later replaces it)
+        plan.pooled = bool(pool)
         if strict:
             self.check(plan)
         return plan
@@ -246,20 +255,29 @@ class Engine:
 
         for _ in range(8):                                       # clocks up before anything is compared
             self.sample(plan)
-        # all candidates stay alive side by side until the choice is made (a freed block would come straight back from
-        # the allocator).  The times fall into groups (on one box 1.25 / 1.51 / 1.67 ms for 7.5 GB of rows): stop at the
-        # first candidate the rows stream into at >= 5.6 TB/s -- the fast group -- and otherwise keep the fastest of all.
-        # (Round 2 stopped at "7 % below the slowest seen", which a still slower outlier satisfied for a slow buffer.)
+        # Draws come one after the other and at most two buffers are alive: the best so far and the candidate.  A released
+        # buffer goes back to the DRIVER (torch.cuda.empty_cache(): torch's cache would hand the very same block to the next
+        # request) and the next allocation is other physical memory -- consecutive draws walk through the device's memory, of
+        # which stretches are fast and stretches are slow (twelve draws on one box: 4 slow, 5 fast, 3 slow; NOTES R4-6).
+        # Stop at the first buffer the rows stream into at >= 0.70 of the HBM peak -- the fast kind -- else keep the fastest.
+        # (Round 3 kept every candidate alive side by side: 4x the row memory; round 2 stopped at "7 % below the slowest
+        # seen", which a still slower outlier satisfied for a slow buffer.)
         row_bytes = float(plan.total_rows) * nat.TRAJ_COLS * 8.0
         fast_ms = row_bytes / (self.FAST_ROW_BUFFER_FRACTION_OF_PEAK * self.hbm_peak_bytes_per_s()) * 1e3
-        candidates, times = [plan.traj], [timed(plan.traj)]
-        while len(candidates) < trials and min(times) > fast_ms:
+        best, times = plan.traj, [timed(plan.traj)]
+        best_t = times[0]
+        while len(times) < trials and best_t > fast_ms:
             try:
-                candidates.append(torch.empty_like(candidates[0]))
-            except RuntimeError:                                 # out of memory: choose among what there is
+                cand = torch.empty_like(best)
+            except RuntimeError:                                 # out of memory: keep what there is
                 break
-            times.append(timed(candidates[-1]))
-        plan.traj = candidates[int(np.argmin(times))]            # (every candidate holds the same rows)
+            times.append(timed(cand))                            # (every candidate holds the same rows afterwards)
+            if times[-1] < best_t:
+                best, best_t = cand, times[-1]
+            del cand
+            plan.traj = best
+            torch.cuda.empty_cache()
+        plan.traj = best
         plan.placement_ms = times
 
     def replan(self, plan: Plan):
