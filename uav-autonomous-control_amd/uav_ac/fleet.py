@@ -220,6 +220,7 @@ class Engine:
         yaw = torch.empty((total,), dtype=torch.float64, **kw) if dense_yaw else None
         first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
         plan = Plan(B, m, float(velocity), float(dt), wp, times, seg_rows, row_offsets, coeffs, status, traj, total, yaw, first_yaw)
+        del traj                                                 # (place_rows may release the first draw: no second reference to it)
         self.sample(plan)
         if int(placement_trials) > 1 and total > 0 and not pooled:
             self.place_rows(plan, int(placement_trials))
@@ -243,18 +244,24 @@ class Engine:
         torch = self._torch
 
         def timed(buf):
+            # The chip's clock sags within milliseconds of idling (an allocation, a device query) and takes ~30 ms of work to come
+            # back: blocks of three sampler runs are timed until two blocks in a row agree to 2 % (ten at most), the last one counts.
             plan.traj = buf
             self.sample(plan)                                    # first touch of fresh pages is not what is compared
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(3):
-                self.sample(plan)
-            b.record()
-            b.synchronize()
-            return a.elapsed_time(b) / 3
+            prev = None
+            for _ in range(10):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    self.sample(plan)
+                b.record()
+                b.synchronize()
+                t = a.elapsed_time(b) / 3
+                if prev is not None and abs(t - prev) <= 0.02 * prev:
+                    break
+                prev = t
+            return t
 
-        for _ in range(8):                                       # clocks up before anything is compared
-            self.sample(plan)
         # Draws come one after the other and at most two buffers are alive: the best so far and the candidate.  A released
         # buffer goes back to the DRIVER (torch.cuda.empty_cache(): torch's cache would hand the very same block to the next
         # request) and the next allocation is other physical memory -- consecutive draws walk through the device's memory, of
