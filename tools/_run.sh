@@ -1,1 +1,2 @@
-bash tools/collect_profiles.sh r04 > gpurun_out/collect_r04.log 2>&1; tail -1 gpurun_out/collect_r04.log
+timeout 1500 python -m pytest tests/test_gpu_planner.py tests/test_gpu_round2.py tests/test_gpu_round3.py tests/test_gpu_facade.py -x -q -m gpu 2>&1 | grep -E "passed|failed|^E" | head
+python tools/solve_time.py 2>/dev/null | grep "B=" > gpurun_out/r04_solve_park.txt; cat gpurun_out/r04_solve_park.txt

@@ -239,9 +239,10 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     double kept[NREG > 0 ? NREG : 1][28];
 
     // ------------------------------------------------------------------ forward sweep over interior knots
+    // ([Ut | rt] of a lane's LAST knot is what its backward sweep starts from: it stays in these registers, never parked)
+    double Ut[4][4], rt[4][3];
     {
         Seg prev, cur;
-        double Ut[4][4], rt[4][3];
         double p0[3] = {w[0], w[1], w[2]}, p1[3] = {w[3], w[4], w[5]};
         build_segment(prev, tm[0], p0, p1);
         // inputs of the knot after this one (clamped reads past the end are never used)
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
             }
             ok = solve4(S, R) && ok;
             double *o = park_at(kk);
-            const bool in_regs = NREG > 0 && kk < NREG;      // (uniform: every lane of a uniform batch is at the same knot)
+            const bool in_regs = (NREG > 0 && kk < NREG) || kk == nk - 1;      // (kk < NREG is uniform: every lane of a uniform batch is at the same knot)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (!in_regs && (PARK_LDS ? lane < NACT : live)) o[(size_t)(16 + i * 3 + a) * pst] = R[i][4 + a]; }
             }
-            if (in_regs) {
+            if (NREG > 0 && kk < NREG) {
 #pragma unroll
                 for (int q = 0; q < NREG; ++q)
                     if (kk == q) {
@@ -340,18 +341,13 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     // on their way while the segment before is computed: [Ut | rt] of knot s - 1, start waypoint and duration of segment s
     double nxt[28], nw[3], nt;
     {
-        const double *o = park_at(nk >= 1 ? nk - 1 : 0);
         if (nk >= 1) {
-            if (NREG > 0 && nk - 1 < NREG) {
 #pragma unroll
-                for (int q = 0; q < NREG; ++q)
-                    if (nk - 1 == q) {
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                        for (int i = 0; i < 28; ++i) nxt[i] = kept[q][i];
-                    }
-            } else {
+                for (int j = 0; j < 4; ++j) nxt[i * 4 + j] = Ut[i][j];
 #pragma unroll
-                for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
+                for (int a = 0; a < 3; ++a) nxt[16 + i * 3 + a] = rt[i][a];
             }
         }
 #pragma unroll
