@@ -496,3 +496,32 @@ def test_host_pointer_obstacle_loop_equals_the_engine(eng, nat):
         eng.ctx.call("uavac_minsnap_obstacle_waypoints", nat.np_ptr(flat), nat.np_ptr(so), B, 3.0, 0.01, nat.np_ptr(lab), len(lab), 10, 0,
                      nat.np_ptr(wp_out), 5, nat.np_ptr(so_out), nat.np_ptr(ok))
     assert so_out[-1] >= so[-1]
+
+
+def test_bench_line_schema_with_extras():
+    """`python bench.py` as the driver runs it (fewer steps): ONE JSON line with the contract's keys, `roofline` and `minsnap` priced
+    both by algorithmic and by counter bytes when profiles/hbm_traffic.json matches the sources, the first allocation's planning
+    rate next to the searched-once leg (two row buffers alive at most), per-launch times, exit code 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-config4"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "minsnap", "build"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 1e10
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and 0.5 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert len(rf["per_launch_ms_one_step"]) == 10 and rf["kernel_vgprs"] <= 256
+    m = d["minsnap"]
+    assert 0.45 < m["frac_first_allocation"] < 0.85 and m["roofline"]["frac"] == m["frac_first_allocation"]
+    once = m["row_buffer_searched_once"]
+    assert once["row_buffers_alive_at_most"] == 2 and 1 <= len(once["sampler_ms_per_draw"]) <= 12 and 0.45 < once["frac"] < 0.85
+    assert once["frac"] >= m["frac_first_allocation"] - 0.03            # a search never ends on a clearly worse buffer than it began with
+    if rf["traffic"] is not None:                                        # profiles/hbm_traffic.json was measured on these sources
+        assert 0.85 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.05 and rf["frac_counter_bytes"] < rf["frac"]
