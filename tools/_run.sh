@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_round3.py -x -q -m gpu -k "bench_line" 2>&1 | grep -E "passed|failed|^E" | head -5
+timeout 600 ./tools/vmm_va_probe.bin > gpurun_out/vmm_va.txt 2>&1; cat gpurun_out/vmm_va.txt
