@@ -1,1 +1,2 @@
-rocm-smi --showmemorypartition --showcomputepartition 2>&1 | grep -v "^=\|^$" | head -12; rocm-smi --showtemp --showclocks 2>&1 | grep -iE "temp|mclk|fclk|sclk|socclk" | head -14; ./tools/vmm_va_probe.bin 2>&1 | sed -n 2,3p | cut -c1-120; rocm-smi --showtemp 2>&1 | grep -iE "temp" | head -6
+timeout 1500 python -m pytest tests/test_gpu_planner.py -x -q -m gpu 2>&1 | grep -E "passed|failed|^E" | head
+python tools/solve_time.py 2>/dev/null | grep "B=" > gpurun_out/r04_solve_park.txt; head -4 gpurun_out/r04_solve_park.txt

@@ -213,7 +213,10 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
     const size_t sB = (size_t)B;
     // where knot k's parked block lives and how far apart its 28 values are
     const size_t pst = PARK_LDS ? (size_t)NACT : sB;
+    // (NREG > 0: knot NREG -- the first one past the registers -- goes to a [28][64] slab of the wave's LDS: launched with 14 KB)
+    auto park_stride = [&](int k_) -> size_t { return (NREG > 0 && k_ == NREG) ? (size_t)TB : pst; };
     auto park_at = [&](int k_) -> double * {
+        if (NREG > 0 && k_ == NREG) return park_lds + threadIdx.x;
         return PARK_LDS ? park_lds + (size_t)k_ * 28 * NACT + (threadIdx.x < NACT ? threadIdx.x : 0) : ws + ((size_t)k_ * 28) * sB + bb;
     };
     int m = m_uniform;
@@ -292,13 +295,14 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
             }
             ok = solve4(S, R) && ok;
             double *o = park_at(kk);
+            const size_t ost = park_stride(kk);
             const bool in_regs = (NREG > 0 && kk < NREG) || kk == nk - 1;      // (kk < NREG is uniform: every lane of a uniform batch is at the same knot)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (!in_regs && (PARK_LDS ? lane < NACT : live)) o[(size_t)(i * 4 + j) * pst] = R[i][j]; }
+                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (!in_regs && (PARK_LDS ? lane < NACT : live)) o[(size_t)(i * 4 + j) * ost] = R[i][j]; }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (!in_regs && (PARK_LDS ? lane < NACT : live)) o[(size_t)(16 + i * 3 + a) * pst] = R[i][4 + a]; }
+                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (!in_regs && (PARK_LDS ? lane < NACT : live)) o[(size_t)(16 + i * 3 + a) * ost] = R[i][4 + a]; }
             }
             if (NREG > 0 && kk < NREG) {
 #pragma unroll
@@ -373,8 +377,9 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
                     }
             } else {
                 const double *o = park_at(s - 2);
+                const size_t ost = park_stride(s - 2);
 #pragma unroll
-                for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * pst];
+                for (int i = 0; i < 28; ++i) nxt[i] = o[(size_t)i * ost];
             }
         }
         if (s >= 1) {
@@ -471,7 +476,11 @@ int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times,
     do {                                                                                                                            \
         if (lanes == 64) UAVAC_SOLVE_LAUNCH(R, P, 64, 0); else if (lanes == 32) UAVAC_SOLVE_LAUNCH(R, P, 32, 0); else UAVAC_SOLVE_LAUNCH(R, P, 16, 0); \
     } while (0)
-    if (keep) UAVAC_SOLVE_LAUNCH(false, false, 64, 5);
+    if (keep) {                                           // (the sixth knot's slab in LDS: 28 x 64 doubles of dynamic shared memory)
+        auto kern = minsnap_solve_bt_kernel<false, false, 64, 5>;
+        hipLaunchKernelGGL(kern, grid, dim3(TB), 28 * TB * sizeof(double), ctx->stream, wp, times, B, m, ctx->d_ws, coeffs, status,
+                           ctx->d_flags, seg_offsets, guard_rows, guard_capacity, active);
+    }
     else if (lds_park) { if (seg_offsets) UAVAC_SOLVE_LANES(true, true); else UAVAC_SOLVE_LANES(false, true); }
     else { if (seg_offsets) UAVAC_SOLVE_LANES(true, false); else UAVAC_SOLVE_LANES(false, false); }
 #undef UAVAC_SOLVE_LANES
