@@ -1,1 +1,1 @@
-bash tools/collect_profiles.sh r04 > gpurun_out/collect_r04.log 2>&1; tail -1 gpurun_out/collect_r04.log; timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -2
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -2; python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
