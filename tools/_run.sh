@@ -1,1 +1,1 @@
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -2; python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_round3.py -x -q -m gpu -k "bench_line" 2>&1 | grep -E "passed|failed|^E" | head -5
