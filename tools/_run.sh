@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_round3.py -x -q -m gpu -k "bench_line" 2>&1 | grep -E "passed|failed|^E" | head -5
+python bench.py --no-config4 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_now.json
