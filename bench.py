@@ -495,11 +495,12 @@ def main():
             sampler_ms[label] = round(a.elapsed_time(b) / 5, 4)
         eng.ctx.set_option("sampler_waves", 4)
         # what a caller gets who pays a search for the row buffer ONCE per process (round-3 VERDICT 5; Engine.place_rows /
-        # plan(..., placement_trials, pool=True)): up to twelve draws one after the other, two row buffers alive at most -- untimed
+        # plan(..., placement_trials, pool=True)): up to 24 draws one after the other (180 GB of the device's memory walked through at
+        # most; twelve were not enough once), two row buffers alive at most -- untimed
         # set-up -- then the same planning chain.  `frac_first_allocation` above stays what the line's `value` was measured with.
         try:
             t_search = time.perf_counter()
-            eng.place_rows(plan, 12)
+            eng.place_rows(plan, 24)
             torch.cuda.synchronize()
             search_s = time.perf_counter() - t_search
             # the planning chain measured as `ms_solve_plus_sample` above is: inside whole steps, between the rollouts of two

@@ -521,7 +521,7 @@ def test_bench_line_schema_with_extras():
     m = d["minsnap"]
     assert 0.45 < m["frac_first_allocation"] < 0.85 and m["roofline"]["frac"] == m["frac_first_allocation"]
     once = m["row_buffer_searched_once"]
-    assert once["row_buffers_alive_at_most"] == 2 and 1 <= len(once["sampler_ms_per_draw"]) <= 12 and 0.45 < once["frac"] < 0.85
+    assert once["row_buffers_alive_at_most"] == 2 and 1 <= len(once["sampler_ms_per_draw"]) <= 24 and 0.45 < once["frac"] < 0.85
     assert once["frac"] >= m["frac_first_allocation"] - 0.03            # a search never ends on a clearly worse buffer than it began with
     if rf["traffic"] is not None:                                        # profiles/hbm_traffic.json was measured on these sources
         assert 0.85 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.05 and rf["frac_counter_bytes"] < rf["frac"]
