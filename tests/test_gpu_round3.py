@@ -525,3 +525,39 @@ def test_bench_line_schema_with_extras():
     assert once["frac"] >= m["frac_first_allocation"] - 0.03            # a search never ends on a clearly worse buffer than it began with
     if rf["traffic"] is not None:                                        # profiles/hbm_traffic.json was measured on these sources
         assert 0.85 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.05 and rf["frac_counter_bytes"] < rf["frac"]
+
+
+def test_full_size_planning_chain_is_the_same_under_every_launch_shape(eng):
+    """BASELINE configs[2] at its full size (65 536 missions of 12 segments, 85.6 M rows): the coefficients of the solve as the
+    launcher shapes it there (five knots in registers, one in LDS, the last never parked) equal those of the plain 64-lane
+    workspace form bit for bit, and the rows of the chunk-streaming sampler equal the one-wave sampler's -- checked through a
+    64-bit checksum per mission of both (size-independent: no second 7.5 GB buffer on the host)."""
+    import torch
+    from bench import missions
+    wps = missions(65536, 12, 0, 65536)
+    plan = eng.plan(wps, 3.0, 0.01)
+
+    def digest():
+        torch.cuda.synchronize()
+        c = plan.coeffs.view(torch.int64).reshape(plan.B, -1).sum(dim=1)
+        rows = plan.traj.view(torch.int64).sum(dim=1)                           # wrap-around int64 sums: a checksum, order-free per row
+        per_mission = torch.zeros(plan.B, dtype=torch.int64, device=rows.device)
+        ids = torch.repeat_interleave(torch.arange(plan.B, device=rows.device), (plan.row_offsets[1:] - plan.row_offsets[:-1]))
+        per_mission.index_add_(0, ids, rows * (torch.arange(rows.numel(), device=rows.device) % 1000003 + 1))
+        return c.clone(), per_mission
+
+    ref_c, ref_r = digest()
+    try:
+        for opts in ({"solve_keep": 0, "solve_lanes": 64, "solve_park": 0, "sampler_waves": 1}, {"solve_keep": 1, "sampler_waves": 2},
+                     {"solve_lanes": 32, "solve_keep": 0, "sampler_waves": 8, "sampler_group": 2}):
+            for k, v in opts.items():
+                eng.ctx.set_option(k, v)
+            plan.coeffs.fill_(float("nan")); plan.traj.fill_(float("nan"))
+            eng.replan(plan)
+            c, r = digest()
+            assert torch.equal(c, ref_c) and torch.equal(r, ref_r), opts
+            for k in opts:
+                eng.ctx.set_option(k, 4 if k == "sampler_waves" else 1 if k == "sampler_group" else -1)
+    finally:
+        for k, v in (("solve_keep", -1), ("solve_lanes", -1), ("solve_park", -1), ("sampler_waves", 4), ("sampler_group", 1)):
+            eng.ctx.set_option(k, v)

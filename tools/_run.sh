@@ -1,1 +1,1 @@
-bash tools/collect_profiles.sh r04 > gpurun_out/collect_r04.log 2>&1; tail -1 gpurun_out/collect_r04.log
+timeout 900 python -m pytest tests/test_gpu_round3.py -x -q -m gpu -k "full_size_planning" 2>&1 | grep -E "passed|failed|^E" | head -8
