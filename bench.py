@@ -26,9 +26,11 @@ rank 0 over RCCL timed and verified) with compute-only and compute+gather rates 
 ROWS (20.8 GB into the root's links) and for the gather of the PLAN (0.4 GB; the root re-samples the peers' rows from
 it, bit-identical -- verified against the row gather in the same run).
 
-Exit status: 0 when the line's `value` (configs[2], no collective in its data path) was measured in full.  A stalled or failed
-gather in the config-4 leg does not take that measurement down with it: the line then carries `gather_error` (and `config4`
-lacks `end_to_end`), stderr says so, and the exit status is 0 -- 3 with UAVAC_BENCH_STRICT=1, and always 3 when a rank died.
+Exit status: 0 when the line's `value` (configs[2], no collective in its data path) was measured in full AND nothing the
+config-4 leg delivered was wrong.  Only a STALLED gather (no completion within 240 s) is soft: the line then carries `gather_error`,
+`gather_error_kind: "stall"`, stderr says so, and the exit status is 0 (3 with UAVAC_BENCH_STRICT=1).  Gathered rows that do not match
+their source, rows re-sampled from the gathered plan that differ from the gathered rows, an exception inside a collective, a rank
+that died: exit status 3, always -- rc 0 means the trajectories on rank 0 were right.
 """
 import argparse
 import hashlib
@@ -61,7 +63,8 @@ CHUNK = 1000
 VELOCITY, DT, F = 3.0, 0.01, 10
 FP64_WAVE_INSTR_PEAK = 39.3e12 / 64  # vector fp64 peak of MI355X_MICROARCH.md: 78.6 TFLOP/s = 39.3 T lane-FMA/s = 614 G wave-instr/s
 GATHER_TIMEOUT_S = 240
-GATHER_FAILURE_EXIT = 3 if os.environ.get("UAVAC_BENCH_STRICT") == "1" else 0     # see the module docstring
+GATHER_STALL_EXIT = 3 if os.environ.get("UAVAC_BENCH_STRICT") == "1" else 0      # a stalled exchange alone is soft (module docstring)
+GATHER_FAILURE_EXIT = 3                                                          # wrong data, a failed collective: never rc 0
 C4_TOTAL, C4_SEGMENTS, C4_TICKS = 262144, 8, 5000           # BASELINE.json configs[3]
 ROLLOUT_SOURCES = ("csrc/control_rollout.hip", "csrc/control_law.h", "csrc/minsnap_eval.h", "csrc/minsnap_yaw.h", "csrc/uavac_internal.h")
 
@@ -439,6 +442,10 @@ def main():
             "build": nat_build_info(),
             "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
                         "ms_solve_plus_sample": plan_avg_s * 1e3,
+                        # the planning chain of every timed step (HIP events round the one C call): the mean above prices `value`;
+                        # median and spread say what the instrument resolves
+                        "ms_median": float(np.median(plan_ms)), "ms_min": float(np.min(plan_ms)), "ms_max": float(np.max(plan_ms)),
+                        "frac_median": plan.algorithmic_bytes / (float(np.median(plan_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "row_buffer": "first allocation (Engine.plan's default: no placement search)",
                         "frac_first_allocation": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
                         "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
@@ -494,31 +501,36 @@ def main():
             torch.cuda.synchronize()
             sampler_ms[label] = round(a.elapsed_time(b) / 5, 4)
         eng.ctx.set_option("sampler_waves", 4)
-        # what a caller gets who pays a search for the row buffer ONCE per process (round-3 VERDICT 5; Engine.place_rows /
-        # plan(..., placement_trials, pool=True)): up to 24 draws one after the other (180 GB of the device's memory walked through at
-        # most; twelve were not enough once), two row buffers alive at most -- untimed
-        # set-up -- then the same planning chain.  `frac_first_allocation` above stays what the line's `value` was measured with.
+        # The same steps once more with the shader clock beside them: one extra wavefront on a side stream stamps s_memtime /
+        # s_memrealtime over the first millisecond of every planning chain and over 10 ms of the flight behind it
+        # (uavac_clock_probe_dev).  Untimed; the steps `value` was measured on carry no probe.  `ms_median` of this leg against
+        # the timed leg's is the instrument's leg-to-leg repeatability on one row buffer.
+        side = torch.cuda.Stream(device=dev)
+        clocked = {"planning_ms": [], "planning_clock_ghz": [], "rollout_ms_per_launch": [], "rollout_clock_ghz": []}
         try:
-            t_search = time.perf_counter()
-            eng.place_rows(plan, 24)
-            torch.cuda.synchronize()
-            search_s = time.perf_counter() - t_search
-            # the planning chain measured as `ms_solve_plus_sample` above is: inside whole steps, between the rollouts of two
-            # flights (planning chains back to back run ~5 % slower on the same buffer: another clock)
-            rec2 = []
-            for _ in range(2):
-                one_step()
-            for _ in range(5):
-                one_step(rec2)
-            torch.cuda.synchronize()
-            pooled_s = float(np.mean([a_.elapsed_time(b_) for a_, b_, _ in rec2])) * 1e-3
-            pooled = {"ms_solve_plus_sample": pooled_s * 1e3, "frac": plan.algorithmic_bytes / pooled_s / 1e9 / HBM_PEAK_GBS,
-                      "segments_per_s": B * SEGMENTS / pooled_s, "sampler_ms_per_draw": [round(x, 4) for x in plan.placement_ms],
-                      "search_s": round(search_s, 3), "row_buffers_alive_at_most": 2,
-                      "note": "row buffer drawn again until the sampler fills it at >= 0.70 of the HBM peak (Engine.place_rows), once; not the "
-                              "configuration `value` was measured in"}
+            for i in range(10):
+                e0, e1, e2 = ev(), ev(), ev()
+                e0.record()
+                side.wait_event(e0)
+                p_plan = eng.clock_probe_begin(1000, stream=side)
+                eng.replan(plan)
+                e1.record()
+                side.wait_event(e1)
+                p_roll = eng.clock_probe_begin(10000, stream=side)
+                fleet.reset()
+                for _ in range(n_chunks):
+                    fleet.rollout(CHUNK, state_log=log)
+                e2.record()
+                torch.cuda.synchronize()
+                if i >= 2:
+                    clocked["planning_ms"].append(round(e0.elapsed_time(e1), 4))
+                    clocked["rollout_ms_per_launch"].append(round(e1.elapsed_time(e2) / n_chunks, 4))
+                    clocked["planning_clock_ghz"].append(round(eng.clock_probe_ghz(p_plan), 3))
+                    clocked["rollout_clock_ghz"].append(round(eng.clock_probe_ghz(p_roll), 3))
+            clocked["ms_median"] = float(np.median(clocked["planning_ms"]))
+            clocked["clock_ghz"] = float(np.median(clocked["planning_clock_ghz"]))
         except Exception as exc:                              # an extra: the line's measurements above must survive it
-            pooled = {"error": f"{type(exc).__name__}: {exc}"}
+            clocked["error"] = f"{type(exc).__name__}: {exc}"
         # the same missions flown at half the speed (velocity 1.5: legs demand < 2.5 m/s^2): nobody departs
         slow = eng.plan(wps, VELOCITY / 2, DT, placement_trials=1)
         fl2 = eng.fleet(slow)
@@ -536,7 +548,11 @@ def main():
         if rank == 0:
             out["roofline"]["per_launch_ms_one_step"] = [round(x, 4) for x in per_launch]
             out["minsnap"]["sampler_ms_on_this_row_buffer"] = sampler_ms
-            out["minsnap"]["row_buffer_searched_once"] = pooled
+            out["minsnap"]["clocked_steps"] = clocked
+            if "clock_ghz" in clocked:
+                out["minsnap"]["clock_ghz"] = clocked["clock_ghz"]
+                out["minsnap"]["leg_to_leg"] = clocked["ms_median"] / out["minsnap"]["ms_median"]
+                out["roofline"]["clock_ghz"] = float(np.median(clocked["rollout_clock_ghz"]))
             out["rollout_only_flyable"] = {"value": B * CHUNK * n_chunks / (a.elapsed_time(b) * 1e-3),
                                            "unit": "UAV control-steps/s per GPU", "velocity": VELOCITY / 2,
                                            "frac_uavs_within_0.5m_of_target_row": kept2,
@@ -550,22 +566,37 @@ def main():
     if not args.no_config4:
         del plan, fleet, log
         torch.cuda.empty_cache()
-        from uav_ac.fleet import balanced_root_share, shard_bounds, shard_sizes
+        from uav_ac.fleet import balanced_root_share, candidate_shard_sizes, measure_tick_table, shard_bounds, shard_sizes
         # contiguous blocks; rank 0 -- the root of the final gather, which takes everybody's rows into its HBM while it flies --
-        # gets a smaller block so that it finishes with its peers (a projection from one-GPU measurements: fleet.py)
-        root_share = balanced_root_share(C4_TOTAL, world, C4_TICKS, C4_SEGMENTS) if (world > 1 and not args.equal_shards) else None
+        # gets a smaller block so that it finishes with its peers.  How much smaller follows from what a shard of n missions costs
+        # on THESE GPUs: every rank measures three candidate sizes (a few tens of ms), the slowest rank's numbers count, and the
+        # table goes into the line (`config4.tick_table`).  UAVAC_BENCH_TICK_TABLE='[[n, us_per_tick, plan_ms_per_1000], ...]'
+        # injects a table instead (tests).
+        root_share, tick_table = None, None
+        if world > 1 and not args.equal_shards:
+            injected = os.environ.get("UAVAC_BENCH_TICK_TABLE")
+            if injected:
+                tick_table = [tuple(float(v) for v in row) for row in json.loads(injected)]
+            else:
+                sizes_c = candidate_shard_sizes(C4_TOTAL, world)
+                mine = measure_tick_table(eng, C4_SEGMENTS, sizes_c, VELOCITY, DT)
+                t = torch.tensor([[us, pm] for _, us, pm in mine], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tick_table = [(n, float(a_), float(b_)) for (n, _, _), (a_, b_) in zip(mine, t.cpu().tolist())]
+            root_share = balanced_root_share(C4_TOTAL, world, C4_TICKS, C4_SEGMENTS, tick_table=tick_table)
         sizes4 = shard_sizes(C4_TOTAL, world, root_share, 0)
         lo4, hi4 = shard_bounds(C4_TOTAL, rank, world, root_share, 0)
         B4 = hi4 - lo4
         wps4 = missions(C4_TOTAL, C4_SEGMENTS, lo4, hi4)
         plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)
         fleet4 = eng.fleet(plan4)
-        log4 = torch.empty((CHUNK, 13, -(-B4 // 16) * 16), dtype=torch.float64, device=dev)     # rows on 128-byte lines for any B4
+        pitch4 = -(-B4 // 16) * 16                                                               # rows on 128-byte lines for any B4
+        log4 = torch.empty((CHUNK, 13, pitch4), dtype=torch.float64, device=dev)
 
         def fly4():
             fleet4.reset()
             for _ in range(C4_TICKS // CHUNK):
-                fleet4.rollout(CHUNK, state_log=log4)
+                fleet4.rollout(CHUNK, state_log=log4, log_pitch=pitch4)
 
         def step4():
             eng.replan(plan4)
@@ -600,6 +631,9 @@ def main():
         c4 = {"workload": "BASELINE.json configs[3]: 262144 UAVs in total (strong scaling), 8-segment missions, plan + "
                           "5000 fused ticks (5 launches x 1000, state logged), trajectories gathered to rank 0",
               "batch_total": C4_TOTAL, "batch_per_gpu": B4, "shard_sizes": sizes4, "root_share": root_share,
+              "tick_table": ([[int(n), round(us, 4), round(pm, 5)] for n, us, pm in tick_table] if tick_table else None),
+              "tick_table_columns": "missions on the GPU, us per logged tick, ms of planning per 1000 missions (max over ranks)",
+              "log_pitch": pitch4,
               "segments": C4_SEGMENTS, "ticks": C4_TICKS,
               "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
               "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel(),
@@ -614,9 +648,10 @@ def main():
                 # a stalled exchange must not lose the measurement -- and must not look like a success either
                 if rank == 0:
                     out["gather_error"] = f"no completion within {GATHER_TIMEOUT_S} s"
+                    out["gather_error_kind"] = "stall"
                     print(json.dumps(out), flush=True)
                     print(f"bench.py: config-4 gather stalled ({GATHER_TIMEOUT_S} s); the headline was measured before it", file=sys.stderr, flush=True)
-                os._exit(GATHER_FAILURE_EXIT)
+                os._exit(GATHER_STALL_EXIT)
             watchdog = threading.Timer(GATHER_TIMEOUT_S, bail)
             watchdog.daemon = True
             watchdog.start()
@@ -639,6 +674,19 @@ def main():
                 else:
                     comm = RcclComm(eng)                   # ncclCommInitRank behind the C ABI; id travels over the process group
                     comm.gather_rows(plan4.traj[:1024], dst=0)      # connection set-up is not part of any timed gather
+                    rccl_ranks, rccl_rank = comm.shape()            # what the communicator itself says (ncclCommCount / UserRank)
+                    if rank == 0:
+                        c4["rccl_ranks"] = rccl_ranks
+                    if (rccl_ranks, rccl_rank) != (world, rank):
+                        raise RuntimeError(f"the RCCL communicator has {rccl_ranks} ranks / this is its rank {rccl_rank}; the process group says {world} / {rank}")
+                # which physical GPU every rank flew on, gathered over the process group: N ranks must name N devices
+                idents = [None] * world
+                dist.all_gather_object(idents, eng.ctx.device_identity())
+                if rank == 0:
+                    c4["devices"] = idents
+                    c4["distinct_devices"] = len({i.split(";")[0] for i in idents})
+                if len({i.split(";")[0] for i in idents}) != world and not rehearsal:
+                    raise RuntimeError(f"{world} ranks on {len(set(idents))} distinct GPUs: {idents}")
 
                     def rows_gather():
                         return comm.gather_rows(plan4.traj, dst=0)
@@ -648,9 +696,13 @@ def main():
 
                 # ---- the gather of the ROWS: once untimed (allocation, verification), then timed
                 gathered, counts = rows_gather()
+                if rank == 0 and (rehearsal or forced) and os.environ.get("UAVAC_BENCH_CORRUPT_GATHER") == "1":
+                    gathered[gathered.shape[0] // 2, 4] += 1.0      # TEST HOOK (rehearsal / forced world 1 only): one wrong value must end in exit 3
                 if rank == 0:
                     own = counts[0]
                     ok = sum(counts) == gathered.shape[0] and bool((gathered[:own] == plan4.traj[:own]).all())
+                    # rank 0's own rows prove nothing about the transfers: every peer's block is checked against ITS rows below
+                    # (first waypoint exactly) and, row for row, against the rows re-sampled from the gathered plan
                     # every peer's block starts with its first mission's first waypoint, at rest
                     offs = np.concatenate([[0], np.cumsum(counts)])
                     starts = [shard_bounds(C4_TOTAL, r, world, root_share, 0)[0] for r in range(world)]
@@ -753,7 +805,8 @@ def main():
             else:                                     # a communicator that failed once may not shut down cleanly
                 sys.stdout.flush()
                 if rank == 0:
-                    print(f"bench.py: config-4 gather failed ({gather_err}); the headline was measured before it", file=sys.stderr, flush=True)
+                    print(f"bench.py: config-4 gather FAILED ({gather_err}); the headline was measured before it; exit {GATHER_FAILURE_EXIT}",
+                          file=sys.stderr, flush=True)
                 os._exit(GATHER_FAILURE_EXIT)
         if gather_err is not None:
             sys.exit(GATHER_FAILURE_EXIT)
@@ -772,6 +825,7 @@ def main():
         return
     if gather_err is not None:
         out["gather_error"] = gather_err
+        out["gather_error_kind"] = "mismatch" if ("do not match" in gather_err or "differ" in gather_err) else "collective"
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(eng, wps)
         out["checks"]["yaw_2pi_forks"] = yaw_fork_census(eng)

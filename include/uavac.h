@@ -38,6 +38,8 @@ extern "C" {
 #define UAVAC_ESINGULAR (-4) /* a mission's knot system is singular (e.g. repeated waypoint) */
 #define UAVAC_ENOMEM (-5)
 #define UAVAC_ECOMM (-6)     /* RCCL error (text in uavac_last_error)              */
+#define UAVAC_ETOOLCHAIN (-7)/* uavac_create's self-check: the device math library's atan2 no longer has the bits this build's
+                                sampler reproduces (rebuild against the new toolchain; text on stderr) */
 
 #define UAVAC_MAX_SEGMENTS 64   /* m, segments per mission                          */
 #define UAVAC_TRAJ_COLS 11      /* x y z vx vy vz ax ay az yaw spline_id: minimum_snap.py:122-123 */
@@ -110,6 +112,15 @@ const char *uavac_last_rollout_kernel(const uavac_ctx *ctx);
 int uavac_last_rollout_vgprs(const uavac_ctx *ctx);
 /* "libuavac <version>; gfx950; HIP <x.y.z>; <compiler version>" of the build (static string). */
 const char *uavac_build_info(void);
+/* Which physical GPU the ctx runs on: "uuid=<32 hex digits>;pci=<domain:bus:device.function>;name=<gcnArchName>" into buf
+ * (NUL-terminated, truncated to n bytes).  The multi-GPU bench gathers one per rank: eight ranks must name eight devices. */
+int uavac_device_identity(uavac_ctx *ctx, char *buf, int n);
+/* The shader clock the chip holds while other work runs: enqueues ONE wavefront on the ctx's stream that stamps
+ * s_memtime (shader cycles) and s_memrealtime (100 MHz) , sleeps until `window_us` of real time have passed and stamps again;
+ * stamps [4] (DEVICE memory, int64) = {cycles0, real0, cycles1, real1}.  Clock = (cycles1 - cycles0) / (real1 - real0) x 100 MHz
+ * (MI355X_MICROARCH.md, DVFS give-back (6)).  Bind the ctx to a side stream (uavac_set_stream) to run it BESIDE the kernels of
+ * interest; it holds one wave slot and issues nothing but s_sleep.  1 <= window_us <= 1 000 000. */
+int uavac_clock_probe_dev(uavac_ctx *ctx, int window_us, int64_t *stamps);
 /* Tuning knobs; results never depend on them (tested bit for bit).  "rollout_align": 1 (default) =
  * precede a rollout launch that writes a log by an empty kernel of the same workgroup shape (one
  * compute + one store wave), which makes the hardware place one wave of each kind on every SIMD

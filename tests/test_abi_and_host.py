@@ -97,6 +97,15 @@ def test_shard_bounds_partition_the_batch():
     s8 = balanced_root_share(262144, 8, 5000, 8)
     assert 0.04 < s8 < 0.09 and balanced_root_share(262144, 1, 5000, 8) == 1.0
     assert balanced_root_share(262144, 2, 5000, 8) <= 0.5 and balanced_root_share(262144, 4, 5000, 8) <= 0.25
+    # round 5: the cost table is an argument (bench.py measures it on the GPUs at hand); the cut follows the table
+    from uav_ac.fleet import DEFAULT_TICK_TABLE, candidate_shard_sizes
+    assert balanced_root_share(262144, 8, 5000, 8, tick_table=DEFAULT_TICK_TABLE) == s8
+    flat = [(n, 1.0, 0.018) for n in (16384, 32768, 37450)]                       # a tick that costs the same at every size:
+    slow_big = [(16384, 0.8, 0.018), (32768, 1.2, 0.018), (37450, 1.5, 0.018)]    # ... against one that grows with the shard
+    assert balanced_root_share(262144, 8, 5000, 8, tick_table=slow_big) > balanced_root_share(262144, 8, 5000, 8, tick_table=flat)
+    assert candidate_shard_sizes(262144, 8) == [16384, 32768, 37450] and candidate_shard_sizes(262144, 2) == [65536, 131072, 262144]
+    with pytest.raises(ValueError):
+        balanced_root_share(262144, 8, 5000, 8, tick_table=[(0, 1.0, 1.0)])
     with pytest.raises(ValueError):
         shard_sizes(10, 2, 1.5)
 
@@ -152,3 +161,41 @@ def test_planning_kernels_keep_their_register_budgets():
         pytest.skip("no build directory / LLVM tools: library was built elsewhere")
     assert len(counts) >= 28 and all(s == 0 for _, _, s in counts)
     assert any(v > 256 for n, v, _ in counts if "minsnap_solve_bt_kernel" in n)          # the five-knot variant really uses the whole file
+
+
+def test_row_prefetch_lands_in_the_carried_registers_and_no_diagnostics_ship():
+    """The row-fed rollout kernels issue their trajectory-row prefetch from inline asm the compiler cannot see in flight; that is
+    right only while the loads land in the very registers row_wait() hands on and nothing touches them in between.  Checked in
+    the disassembly of every row-fed variant (the third check of __graft_entry__.build()), together with: the shipped library
+    exports no uavac_diag_* symbol, the product kernels carry no UAVAC_DIAG block, and the Makefile turns inline-asm warnings
+    (a clobber the compiler will not honour) into errors."""
+    from uav_ac import _buildcheck
+    if not os.path.exists(os.path.join(PKG, "build", "control_rollout.o")):
+        pytest.skip("no object files here (library built elsewhere)")
+    assert _buildcheck.check_row_prefetch() == 16
+    assert _buildcheck.check_no_diagnostics() is True
+    for name in os.listdir(os.path.join(PKG, "csrc")):
+        with open(os.path.join(PKG, "csrc", name)) as f:
+            assert "UAVAC_DIAG" not in f.read(), name
+    with open(os.path.join(PKG, "Makefile")) as f:
+        assert "-Werror=inline-asm" in f.read()
+
+
+def test_row_prefetch_check_catches_a_copy_made_too_early(tmp_path):
+    """The disassembly check fails when an instruction reads a row register between the loads and their wait."""
+    from uav_ac import _buildcheck
+    kernels = _buildcheck._disassemble(os.path.join(PKG, "build", "control_rollout.o"))
+    if kernels is None:
+        pytest.skip("no object file / LLVM tools here")
+    name, ins = next((n, i) for n, i in kernels.items() if "control_rollout_kernel" in n and "ELb0ELb0ELb0ELi0E" in n)
+    at = max(j for j, x in enumerate(ins) if _buildcheck._ROW_LOAD.match(x) and "offset:64" in x)
+    reg = _buildcheck._ROW_LOAD.match(ins[at]).group(1)
+    tampered = dict(kernels)
+    tampered[name] = ins[:at + 1] + [f"v_mov_b32_e32 v255, v{reg}"] + ins[at + 1:]
+    real = _buildcheck._disassemble
+    _buildcheck._disassemble = lambda obj: tampered
+    try:
+        with pytest.raises(RuntimeError, match="touches a row register"):
+            _buildcheck.check_row_prefetch()
+    finally:
+        _buildcheck._disassemble = real

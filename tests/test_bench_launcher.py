@@ -58,13 +58,24 @@ def test_rehearsal_ranks_through_the_self_launcher_plan_gather_equals_row_gather
     equal blocks with --equal-shards; the rows AND the plan are gathered; rank 0 re-samples the peers' rows from the peers'
     coefficients and finds them bit-identical to the rows the peers sent."""
     from uav_ac.fleet import balanced_root_share, shard_sizes
-    r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-extras"], UAVAC_BENCH_REHEARSAL="1")
+    # n = 2: the shards are cut from what the ranks MEASURE on their GPU at start-up (round-4 VERDICT 7); n = 3: from a table the
+    # test injects.  Either way the line says which table was used and the cut follows from it.
+    table = [[30000, 0.9, 0.02], [90000, 1.7, 0.018], [140000, 2.7, 0.018]]
+    extra = {} if n == 2 else {"UAVAC_BENCH_TICK_TABLE": json.dumps(table)}
+    r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-extras"], UAVAC_BENCH_REHEARSAL="1", **extra)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == n and "REHEARSAL" in line and "gather_error" not in line
     c4 = line["config4"]
-    sizes = shard_sizes(262144, n, balanced_root_share(262144, n, 5000, 8), 0)
-    assert c4["shard_sizes"] == sizes and c4["batch_per_gpu"] == sizes[0] < min(sizes[1:]) and sum(sizes) == 262144
+    if n == 3:
+        assert c4["tick_table"] == table
+    else:
+        assert [row[0] for row in c4["tick_table"]] == [65536, 131072, 262144] and all(us > 0 and pm > 0 for _, us, pm in c4["tick_table"])
+    sizes = shard_sizes(262144, n, balanced_root_share(262144, n, 5000, 8, tick_table=c4["tick_table"]), 0)
+    assert all(abs(a - b) <= 2 for a, b in zip(c4["shard_sizes"], sizes))       # (the line's table is rounded to 4 digits)
+    sizes = c4["shard_sizes"]
+    assert c4["batch_per_gpu"] == sizes[0] < min(sizes[1:]) and sum(sizes) == 262144
+    assert len(c4["devices"]) == n and c4["distinct_devices"] == 1 and "rccl_ranks" not in c4       # ranks share the GPU, gloo
     assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True
     assert c4["plan_gather_ms"] > 0 and c4["steps_per_s_with_plan_gather"] > 0
     if n == 2:                                  # the same with equal blocks
@@ -73,6 +84,22 @@ def test_rehearsal_ranks_through_the_self_launcher_plan_gather_equals_row_gather
         c4 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["config4"]
         assert c4["shard_sizes"] == [131072, 131072] and c4["root_share"] is None
         assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True
+
+
+@pytest.mark.gpu
+def test_rehearsal_with_one_wrong_gathered_value_exits_3():
+    """First contact with eight GPUs is the driver's run: rc 0 must mean the gathered rows were right.  Two ranks on one GPU, one
+    value of a PEER's gathered block changed on rank 0 before the verification (UAVAC_BENCH_CORRUPT_GATHER, honoured in rehearsal /
+    forced-world-1 runs only): the re-sampled plan no longer equals the gathered rows, the line is still printed with the
+    headline and says `mismatch`, every rank exits 3 and so does the launcher -- without UAVAC_BENCH_STRICT."""
+    table = [[30000, 0.9, 0.02], [140000, 2.7, 0.018]]
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--equal-shards"], UAVAC_BENCH_REHEARSAL="1",
+             UAVAC_BENCH_CORRUPT_GATHER="1", UAVAC_BENCH_TICK_TABLE=json.dumps(table))
+    assert r.returncode == 3, (r.returncode, (r.stdout + r.stderr)[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["gather_error_kind"] == "mismatch" and "differ" in line["gather_error"] and line["value"] > 0
+    assert line["config4"]["plan_gather_verified"] is False and "end_to_end" not in line["config4"]
+    assert "FAILED" in r.stderr
 
 
 @pytest.mark.gpu
@@ -90,6 +117,7 @@ def test_two_real_gpus_over_rccl_when_the_box_has_them():
     c4 = line["config4"]
     assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True and "overlap_error" not in c4
     assert c4["plan_overlapped_verified"] is True and c4["overlapped_verified"] is True
+    assert c4["rccl_ranks"] == 2 and c4["distinct_devices"] == 2 and len(c4["tick_table"]) == 3
 
 
 def test_ranks_started_by_torch_distributed_run_are_not_launched_again():

@@ -506,7 +506,7 @@ def test_plan_fed_rollout_equals_row_fed_rollout(eng):
         # the same with the compute wave evaluating the rows: coefficients on the spot (0, round 3's form, what a full chip uses)
         # or by LDS-DMA an outer tick ahead (1, what a chip with three workgroups per CU uses): the same bits
         try:
-            for mode, suffix in ((0, ""), (1, ", 1")):
+            for mode, suffix in ((0, ", 0"), (1, ", 1")):
                 eng.ctx.set_option("coeff_dma", mode)
                 for yaw_from in ("scan", "column"):
                     e = eng.fleet(plan, from_plan=True, yaw_from=yaw_from)

@@ -46,6 +46,17 @@ def test_bench_multi_gpu_path_on_real_rccl_at_world_1():
     # round 3: the gather of the plan + re-sampling on the root, verified bit for bit against the gathered rows
     assert c4["plan_gather_verified"] is True and c4["plan_gather_ms"] > 0 and c4["steps_per_s_with_plan_gather"] > 0
     assert c4["plan_overlapped_verified"] is True and "overlap_error" not in c4
+    # round 5: what RCCL and HIP themselves saw -- one rank in the communicator, one named device
+    assert c4["rccl_ranks"] == 1 and len(c4["devices"]) == 1 and c4["distinct_devices"] == 1 and c4["devices"][0].startswith("uuid=")
+    assert c4["log_pitch"] == 262144 and c4["tick_table"] is None and c4["root_share"] is None      # one rank: nothing to balance
+    # ... and ONE wrong value among the gathered rows ends in exit status 3 with the line still printed (round-4 VERDICT 3)
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extras"], env=dict(env, UAVAC_BENCH_CORRUPT_GATHER="1", MASTER_PORT="29534"),
+                         capture_output=True, text=True, timeout=900)
+    assert bad.returncode == 3, (bad.returncode, bad.stderr[-1500:])
+    line = json.loads([l for l in bad.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["gather_error_kind"] == "mismatch" and line["config4"]["gather_verified"] is False and line["value"] > 0
+    assert "end_to_end" not in line["config4"]
 
 
 def test_rccl_world1_gather_and_loopback(eng, nat):
@@ -59,7 +70,9 @@ def test_rccl_world1_gather_and_loopback(eng, nat):
     try:
         w, r = C.c_int(-1), C.c_int(-1)
         eng.ctx.call("uavac_comm_shape", comm._h, C.byref(w), C.byref(r))
-        assert (w.value, r.value) == (1, 0)
+        assert (w.value, r.value) == (1, 0) == comm.shape()
+        ident = eng.ctx.device_identity()
+        assert ident.startswith("uuid=") and ";pci=" in ident and "gfx950" in ident
         assert comm.counts(12345) == [12345]
         rows = torch.randn((70001, 11), dtype=torch.float64, device=eng.device)
         out, counts = comm.gather_rows(rows, dst=0)
@@ -226,7 +239,7 @@ def test_rollout_aligner_launch_does_not_change_a_bit(nat):
         fleet = e.fleet(plan)
         slog, _ = fleet.rollout(K, state_log=True)
         # (a full chip: the compute wave evaluates the target rows, coefficients through registers -- no ninth argument)
-        assert e.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, true, false, true>"
+        assert e.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, true, false, true, 0>"
         logs.append((slog, fleet.state.clone(), fleet.istate.clone()))
         del fleet, plan
     assert torch.equal(logs[1][0], logs[0][0]) and torch.equal(logs[1][1], logs[0][1]) and torch.equal(logs[1][2], logs[0][2])
@@ -257,7 +270,7 @@ def test_ground_takeoff_matches_oracle_and_free_flight_is_untouched(eng, nat):
     eng._bind_stream()
     eng.ctx.call("uavac_state_init_dev", C.byref(V), P(pos), 1, 0, P(state), P(istate))
     eng.ctx.call("uavac_control_rollout_dev", C.byref(V), P(rows), P(offs), P(state), P(istate), 1, K, P(log), None, None, 0)
-    assert eng.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, false, true, false>"
+    assert eng.ctx.last_rollout_kernel() == "control_rollout_kernel<1, 1, true, false, false, false, true, false, 0>"
     Vc = cc.Vehicle.default()
     Vc.ground = 1
     s0, i0 = cc.initial_state(traj[0, 0:3], Vc, hover=False)

@@ -68,7 +68,8 @@ def main():
            "units": "WRITE_SIZE / FETCH_SIZE are KiB; bytes = value * 1024; FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B); SQ_INSTS_VALU is a plain count (the CSV column name says KiB for all rows)",
            "rollout_source_sha": rollout_source_sha(),
            "planning_source_sha": planning_source_sha(),
-           "git": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None}
+           # (no .git on the GPU box: the caller passes the commit the snapshot was taken from, `UAVAC_GIT_HEAD=$(git rev-parse --short HEAD)`)
+           "git": os.environ.get("UAVAC_GIT_HEAD") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None}
     rows = [["kernel", "counter", "dispatches", "mean_value_KiB", "min_KiB", "max_KiB"]]
     for (key, name), vals in sorted(w.items()):
         fv = f.get((key, name), [])

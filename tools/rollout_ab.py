@@ -1,6 +1,7 @@
 """The bench's rollout launch (B = 65 536, m = 12, 1 000 logged ticks, plan-fed) through two builds of the library in ONE process,
 alternating: the in-tree libuavac.so against another build of the same C ABI (default tools/ab/libuavac_r02.so = round 2's last
-commit, `git archive 54af699 | make`).  Both see the same device buffers.   python3 tools/rollout_ab.py [other.so] [B]"""
+commit, `git archive 54af699 | make`).  Both see the same device buffers.   python3 tools/rollout_ab.py [other.so] [B] [plan|rows]
+(`rows`: the row-fed kernel -- uavac_control_rollout_dev on the sampled trajectory -- whatever the batch size.)"""
 import ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
@@ -9,6 +10,7 @@ from bench import missions
 from uav_ac import _native as nat                     # the Vehicle structure only: both libraries are loaded RTLD_LOCAL below
 other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "ab", "libuavac_r02.so")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+FEED = sys.argv[3] if len(sys.argv) > 3 else "plan"
 m, K = 12, 1000
 torch.cuda.set_device(0)
 _P = C.c_void_p
@@ -23,6 +25,7 @@ for name, lib in libs.items():
     lib.uavac_minsnap_solve_dev.argtypes = [_P, _P, _P, C.c_int, C.c_int, _P, _P]
     lib.uavac_minsnap_sample_derivs_dev.argtypes = [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]
     lib.uavac_state_init_dev.argtypes = [_P, C.POINTER(nat.Vehicle), _P, C.c_int, C.c_int, _P, _P]
+    lib.uavac_control_rollout_dev.argtypes = [_P, C.POINTER(nat.Vehicle), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]
     lib.uavac_control_rollout_plan_dev.argtypes = [_P, C.POINTER(nat.Vehicle), _P, _P, _P, _P, _P, C.c_int, C.c_double, _P, _P,
                                                    C.c_int, C.c_int, _P, _P, _P, C.c_int]
     h = _P()
@@ -50,7 +53,8 @@ rows = torch.empty((int(plan.row_offsets[-1].item()), 11), dtype=torch.float64, 
 assert L.uavac_minsnap_sample_derivs_dev(H, p(plan.coeffs), p(plan.seg_rows), p(plan.row_offsets), B, m, 0.01, p(rows), None,
                                          p(plan.first_yaw), None, None) == 0
 torch.cuda.synchronize()
-del rows
+if FEED != "rows":
+    del rows
 V = nat.Vehicle()
 libs["tree"].uavac_vehicle_default(C.byref(V))
 state = torch.empty((30, B), dtype=torch.float64, device="cuda:0")
@@ -63,6 +67,9 @@ def fly(name, launches):
     lib, h = libs[name], ctxs[name]
     assert lib.uavac_state_init_dev(h, C.byref(V), p(pos), B, 1, p(state), p(istate)) == 0
     for _ in range(launches):
+        if FEED == "rows":
+            assert lib.uavac_control_rollout_dev(h, C.byref(V), p(rows), p(plan.row_offsets), p(state), p(istate), B, K, p(log), None, None, 0) == 0
+            continue
         assert lib.uavac_control_rollout_plan_dev(h, C.byref(V), p(plan.coeffs), p(plan.seg_rows), p(plan.row_offsets), None,
                                                   p(plan.first_yaw), m, 0.01, p(state), p(istate), B, K, p(log), None, None, 0) == 0
 
@@ -80,6 +87,6 @@ for rnd in range(8):
         torch.cuda.synchronize()
         res[name].append(a.elapsed_time(b) / 10)
         final[name] = state.clone()
-print(json.dumps({"B": B, "other": os.path.basename(other), "same_bits": bool(torch.equal(final["tree"][:26], final["other"][:26])),
+print(json.dumps({"B": B, "feed": FEED, "other": os.path.basename(other), "same_bits": bool(torch.equal(final["tree"][:26], final["other"][:26])),
                   "ms_per_launch_tree": [round(x, 4) for x in res["tree"]], "ms_per_launch_other": [round(x, 4) for x in res["other"]],
                   "median_tree": round(sorted(res["tree"])[4], 4), "median_other": round(sorted(res["other"])[4], 4)}))

@@ -168,9 +168,81 @@ __global__ void probe_heading_kernel(const double *__restrict__ y, const double 
     }
 }
 
+// uavac_create's self-check of that agreement: 2^16 operand pairs from a counter-based generator (magnitudes over the whole
+// exponent range, both signs) plus every pairing of the special values; counts the pairs whose bits differ.
+__device__ __forceinline__ unsigned long long selfcheck_mix(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void heading_selfcheck_kernel(int n_random, int32_t *__restrict__ mismatches) {
+    const double special[12] = {0.0, -0.0, 1.0, -1.0, __builtin_inf(), -__builtin_inf(), __builtin_nan(""), 4.9406564584124654e-324,
+                                -2.2250738585072014e-308, 1.7976931348623157e308, 1e-3, -3.0};
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double y, x;
+    if (i < n_random) {
+        const unsigned long long a = selfcheck_mix(2ull * i), b = selfcheck_mix(2ull * i + 1);
+        if (i & 1) {                      // any finite bit pattern
+            y = __longlong_as_double((long long)(a & ~(0x7ffull << 52)) | (long long)((a >> 52) % 2047ull) << 52);
+            x = __longlong_as_double((long long)(b & ~(0x7ffull << 52)) | (long long)((b >> 52) % 2047ull) << 52);
+        } else {                          // velocities as the sampler sees them: a few m/s, either sign
+            y = ((double)(a >> 11) * 0x1p-53 - 0.5) * 12.0;
+            x = ((double)(b >> 11) * 0x1p-53 - 0.5) * 12.0;
+        }
+    } else if (i < n_random + 144) {
+        y = special[(i - n_random) / 12];
+        x = special[(i - n_random) % 12];
+    } else {
+        return;
+    }
+    const double mine = uavac_yaw::heading(y, x), lib = atan2(y, x);
+    const bool same = __double_as_longlong(mine) == __double_as_longlong(lib) || (mine != mine && lib != lib);
+    if (!same) atomicAdd(mismatches, 1);
+}
+
+// One wave that stamps shader cycles and real time, sleeps through `ticks_100mhz` of real time and stamps again (uavac_clock_probe_dev).
+__global__ void __launch_bounds__(64) clock_probe_kernel(long long ticks_100mhz, long long *__restrict__ stamps) {
+    const long long c0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    long long r1 = r0;
+    while (r1 - r0 < ticks_100mhz) {
+        __builtin_amdgcn_s_sleep(32);                      // ~2 k cycles without an instruction issued
+        r1 = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    const long long c1 = (long long)__builtin_amdgcn_s_memtime();
+    r1 = (long long)__builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[0] = c0; stamps[1] = r0; stamps[2] = c1; stamps[3] = r1; }
+}
+
 }  // namespace
 
+int uavac_heading_selfcheck(uavac_ctx *ctx, int *mismatches) {
+    constexpr int kRandom = 1 << 16;
+    int32_t *d = nullptr;
+    if (hipMalloc(&d, sizeof(int32_t)) != hipSuccess) return UAVAC_EHIP;
+    int32_t h = -1;
+    bool ok = hipMemsetAsync(d, 0, sizeof(int32_t), ctx->stream) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(heading_selfcheck_kernel, dim3((kRandom + 144 + 255) / 256), dim3(256), 0, ctx->stream, kRandom, d);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&h, d, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok) return UAVAC_EHIP;
+    *mismatches = h;
+    return UAVAC_OK;
+}
+
 extern "C" {
+
+int uavac_clock_probe_dev(uavac_ctx *ctx, int window_us, int64_t *stamps) {
+    UAVAC_ENTER(ctx);
+    if (!stamps || window_us < 1 || window_us > 1000000) return uavac_fail(ctx, UAVAC_EINVAL, "null stamps or window outside 1 us .. 1 s");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)window_us * 100, (long long *)stamps);
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;
+}
 
 int uavac_probe_heading_dev(uavac_ctx *ctx, const double *y, const double *x, int64_t n, double *heading, double *library) {
     UAVAC_ENTER(ctx);

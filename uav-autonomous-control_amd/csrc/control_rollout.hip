@@ -33,18 +33,6 @@
 #include <cmath>
 #include <cstdlib>
 
-#ifdef UAVAC_DIAG_STAMPS      // DIAGNOSTIC builds only (tools/tick_stamps_probe.py): where a tick's cycles go, per workgroup
-__device__ long long g_uavac_diag[8192 * 8];
-__device__ long long g_uavac_diag2[8192 * 4];
-#define DIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())
-extern "C" int uavac_diag_read(long long *out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uavac_diag), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -3;
-}
-extern "C" int uavac_diag_read2(long long *out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uavac_diag2), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -3;
-}
-#endif
-
 namespace {
 
 using namespace uavac_dev;
@@ -57,18 +45,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // flight across ticks makes it put `s_waitcnt vmcnt(0)` at every join of the tick loop (its registers are
 // loop-carried).  Issued from inline asm the load is invisible to that pass; the registers are touched by
 // nothing until row_wait(), which every later read is data-dependent on.
-// (The outputs are "=&v": with "+v" -- the form that GUARANTEES the loads land in the loop-carried registers, see seg_rows_issue --
-// the row-fed tick is 1.3 % longer at every batch size below a full chip (0.766 against 0.756 ms per 1 000 ticks at 4 096 UAVs),
-// and the bit-identity tests against the plan-fed kernels and the oracle would catch a copy made too early.)
+// The operands are "+v": the loads land IN the loop-carried registers.  (An output-only operand may be given a register of its own and
+// copied into the carried one right away, before the data has arrived -- it happened once, NOTES R4-4.)  uav_ac/_buildcheck.py
+// disassembles every row-fed variant and fails the build when anything but these loads writes the destination registers or anything
+// reads them other than behind row_wait()'s s_waitcnt.
 struct RowRegs { u32x4 q[5]; };          // columns 0..9 of a row (x y z vx vy vz ax ay az yaw): 80 bytes
 
 __device__ __forceinline__ void row_issue(RowRegs &r, const double *p) {
+    // (the row consumed last is dead from here on: an empty block "defines" the five register groups anew, so that they are
+    // not kept alive -- as inputs of the loads below -- through the outer block that has just used them: 1.5 % of a row-fed tick)
+    asm volatile("" : "=v"(r.q[0]), "=v"(r.q[1]), "=v"(r.q[2]), "=v"(r.q[3]), "=v"(r.q[4]));
     asm volatile("global_load_dwordx4 %0, %5, off\n\t"
                  "global_load_dwordx4 %1, %5, off offset:16\n\t"
                  "global_load_dwordx4 %2, %5, off offset:32\n\t"
                  "global_load_dwordx4 %3, %5, off offset:48\n\t"
                  "global_load_dwordx4 %4, %5, off offset:64"
-                 : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.q[3]), "=&v"(r.q[4])
+                 : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]), "+v"(r.q[4])
                  : "v"(p)
                  : "memory");
 }
@@ -87,19 +79,25 @@ template <class T> __device__ __forceinline__ void settle(T &x) { asm volatile("
 // advances by 1024 - 16 per instruction.  Masked-off lanes keep their column (tools/scratch/ldsdma_gather_probe.hip).
 // Like the row prefetch the loads are invisible to the compiler's vmcnt bookkeeping; `plan_loads_wait` covers them.
 __device__ __forceinline__ void coeffs_dma(const double *src, unsigned tile_lds_bytes) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:16\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:32\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:48\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:64\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:80\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:96\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:112\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:128\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:144\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:160\n\t"
-                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off offset:176"
-                 : : "v"(src), "s"(tile_lds_bytes) : "memory", "m0", "scc");
+    // M0 is a register the compiler reserves for itself: it takes no clobber for it ("inline asm clobber list contains reserved
+    // registers: m0"), so the block saves it in a scalar register of its own and puts it back -- whatever the compiler keeps
+    // there survives.  (The DMA instructions read M0 when they issue; the value may change behind them.)
+    unsigned saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:16\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:32\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:48\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:64\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:80\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:96\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:112\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:128\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:144\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:160\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off offset:176\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "v"(src), "s"(tile_lds_bytes) : "memory", "scc");
 }
 // the row count of the segment AFTER the one just entered: needed a whole segment later
 // ("+v": the load lands IN the loop-carried register; an output-only operand may get a register of its own and be copied
@@ -160,6 +158,10 @@ constexpr int poly_tile_doubles(bool yawscan) { return (24 + (yawscan ? 0 : 16))
 // functions (minsnap_yaw.h; the sampler sums the corrections in the same left-to-right order).  Rows before a mission's
 // first heading take P.first_yaw[b].  A cursor that does not match the carried scan (a caller moved it, another kernel
 // advanced it) is caught at launch and the scan is rebuilt from row 0.  No yaw bytes are read or written at all.
+// (The heading here is the device library's atan2, the sampler's is uavac_yaw::heading(): the same operations in the same order by
+// construction, with the library's version inlined by the compiler.  Both written as heading() the plan-fed kernels need 257-260
+// vector registers -- one wave per SIMD -- so the agreement is CHECKED instead: uavac_create() runs both over 2^16 operand pairs
+// and every special value and refuses to hand out a context (UAVAC_ETOOLCHAIN) when a single bit differs.)
 template <int CW, int SW, bool LOG_STATE, bool LOG_CMD, bool AABB, bool POLY, bool GROUND, bool YAWSCAN, int PMODE = 0>
 __global__ void __launch_bounds__((LOG_STATE || LOG_CMD || AABB) ? 64 * CW + 128 : 64 * CW)       // compute [+ placeholder] + store
 control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int64_t *__restrict__ row_offsets,
@@ -356,19 +358,8 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             settle(t_srows_nx); settle(t_idx); settle(t_phase); settle(t_yprev); settle(t_ysum); settle(t_first_yaw);
             lds_barrier();                         // the first target row is in its tile (the compute wave waits here too)
         }
-#ifdef UAVAC_DIAG_STAMPS
-        long long dg_wait = 0, dg_issue = 0;
-        const long long dg_t0 = DIAG_NOW();
-#endif
         for (int k = 0; k < K; ++k) {
-#ifdef UAVAC_DIAG_STAMPS
-            const long long dg_a = DIAG_NOW();
-            lds_barrier();
-            const long long dg_b = DIAG_NOW();
-            dg_wait += dg_b - dg_a;
-#else
             lds_barrier();                                             // slab k&1 is complete (stores of earlier ticks stay in flight)
-#endif
             const double *src = slab + (size_t)((kk + k) & 1) * NR * NU + lane;
             // one log (13 or 12 rows) at a time: every LDS read first, then every store, so that neither the
             // LDS latency nor the store path's acceptance time is paid per element
@@ -376,12 +367,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 double v[13];
 #pragma unroll
                 for (int r = 0; r < 13; ++r) v[r] = src[r * NU];
-#ifdef UAVAC_DIAG_LOG_WRAP      // DIAGNOSTIC builds only (tools/log_wrap_probe.sh): every tick overwrites the first UAVAC_DIAG_LOG_WRAP log slots,
-                                // so the log stream stays in L2 instead of reaching HBM -- same instructions, same store path in the CU
-                double *dst = state_log + (size_t)(k % UAVAC_DIAG_LOG_WRAP) * 13 * sP + col0;
-#else
                 double *dst = state_log + (size_t)k * 13 * sP + col0;               // wave-uniform: lives in SGPRs
-#endif
 #pragma unroll
                 for (int r = 0; r < 13; ++r) {
                     if (full || mine) store_uniform_base(dst + r * sP, lane_bytes, v[r]);      // 512-B coalesced wave store
@@ -427,9 +413,6 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 for (int r = 0; r < UAVAC_CMD_COLS; ++r)
                     if (full || mine) store_uniform_base(dst + r * sP, lane_bytes, v[r]);
             }
-#ifdef UAVAC_DIAG_STAMPS
-            dg_issue += DIAG_NOW() - dg_b;
-#endif
             if (TGW) {
                 constexpr int kStoresPerTick = (LOG_STATE ? 13 : 0) + (LOG_CMD ? UAVAC_CMD_COLS : 0);
                 if (t_phase == 0 && t_nrows > 0) {
@@ -488,12 +471,6 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             }
         }
         if (TGW) store_wave_loads_wait<0>(t_srows_nx);       // nothing stays in flight into the tile the next pass reloads
-#ifdef UAVAC_DIAG_STAMPS
-        if (lane == 0 && blockIdx.x < 8192) {
-            g_uavac_diag[blockIdx.x * 8 + 3] = dg_issue;
-            g_uavac_diag[blockIdx.x * 8 + 4] = DIAG_NOW() - dg_t0;
-        }
-#endif
         if (AABB_HERE && mine) istate[2 * sB + col0 + lane] = coll;
       }
         return;
@@ -559,7 +536,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 
     constexpr bool BOX_HERE = AABB && !((LOG_STATE || WATCH) && CW == SW);
 
-    RowRegs nxt;
+    RowRegs nxt = {};
     if (!POLY && nrows > 0) row_issue(nxt, rows + (size_t)min(max(idx, 0), nrows - 1) * UAVAC_TRAJ_COLS);
 
     // POLY: segment / row-in-segment of the cursor, the segment's coefficients and the next 16 yaws, in LDS
@@ -644,21 +621,10 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     // TGW: the target row of the next outer tick, put there by the second wave (which also owns the cursor)
     const double *tgt = slab + (size_t)2 * NR * NU + (size_t)CW * poly_tile_doubles(YAWSCAN) + (tid & 63);
     if (TGW) lds_barrier();                        // the first row is in the tile
-#ifdef UAVAC_DIAG_STAMPS
-    long long dgc_wait = 0, dgc_seg[4] = {0, 0, 0, 0}, dgc_out[4] = {0, 0, 0, 0};
-    const long long dgc_t0 = DIAG_NOW();
-    long long dgc_last = dgc_t0;
-#endif
     for (int k = 0; k < K; ++k) {
         if (phase == 0 && nrows > 0) {
             // ------------------------------------------------------------- outer loop (main.py:47-61)
             double tg_x, tg_y, tg_z, tg_vx, tg_vy, tg_vz, tg_ax, tg_ay, tg_az, tg_yaw;
-#ifdef UAVAC_DIAG_STAMPS
-            const long long dg_o0 = DIAG_NOW();
-#endif
-#ifdef UAVAC_DIAG_SKIP_TARGET     // DIAGNOSTIC (wrong results): what a tick costs when somebody else evaluates the target row
-            if (POLY && k >= V.F) { tg_x = px; tg_y = py; tg_z = pz; tg_vx = 0; tg_vy = 0; tg_vz = 0; tg_ax = 0; tg_ay = 0; tg_az = 0; tg_yaw = first_yaw; } else
-#endif
             if (TGW) {
                 tg_x = tgt[0]; tg_y = tgt[64]; tg_z = tgt[128]; tg_vx = tgt[192]; tg_vy = tgt[256]; tg_vz = tgt[320];
                 tg_ax = tgt[384]; tg_ay = tgt[448]; tg_az = tgt[512]; tg_yaw = tgt[576];
@@ -686,18 +652,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 tg_yaw = row_col(nxt, 9);
             }
 
-#ifdef UAVAC_DIAG_STAMPS
-            asm volatile("" : "+v"(tg_x), "+v"(tg_yaw), "+v"(tg_az));
-            const long long dg_o1 = DIAG_NOW();
-            dgc_out[0] += dg_o1 - dg_o0;                                 // the target row: evaluation + yaw (POLY) or wait for the prefetched row
-#endif
             const VehK O = outer_constants();
-#ifdef UAVAC_DIAG_STAMPS
-            double o_probe = O.g + O.kp_yaw + O.kd_z;                   // the scalar loads have landed
-            asm volatile("" : "+v"(o_probe));
-            const long long dg_o2 = DIAG_NOW();
-            dgc_out[1] += dg_o2 - dg_o1;                                 // constants of the outer loop from the kernarg segment (scalar loads)
-#endif
             const Rot R = quat_to_rot(q0, q1, q2, q3);                 // shared by altitude and attitude
             thrust_cmd = altitude(O, tg_z, tg_vz, tg_az, pz, vz, R.r22, integ);
             double bxc, byc;
@@ -706,11 +661,6 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             double psi, cth, sphi, cphi;
             euler_trig(q0, q1, q2, q3, psi, cth, sphi, cphi);
             rc = yaw_rate(O, tg_yaw, psi, cth, sphi, cphi, qc);
-#ifdef UAVAC_DIAG_STAMPS
-            asm volatile("" : "+v"(rc), "+v"(pc), "+v"(qc), "+v"(thrust_cmd));
-            const long long dg_o3 = DIAG_NOW();
-            dgc_out[2] += dg_o3 - dg_o2;                                 // altitude, lateral, attitude, yaw rate
-#endif
             // next row (main.py:61), consumed F ticks from now; issued last so that nothing in this block
             // still reads the registers it overwrites
             if (TGW) {
@@ -735,34 +685,16 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
                 idx = min(idx + 1, nrows - 1);
                 row_issue(nxt, rows + (size_t)idx * UAVAC_TRAJ_COLS);
             }
-#ifdef UAVAC_DIAG_STAMPS
-#if UAVAC_DIAG_STAMPS > 1     // 2: also wait for what the block issued (exposes the latency of the loads it started)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-            dgc_out[3] += DIAG_NOW() - dg_o3;                            // cursor advance; a lane that enters a new segment loads its coefficients
-#endif
         }
 
         // ----------------------------------------------------------------- inner loop, every tick
-#ifdef UAVAC_DIAG_STAMPS
-        const long long dg_s0 = DIAG_NOW();
-        dgc_seg[0] += dg_s0 - dgc_last;               // what lies between two ticks: loop control + (every F-th tick) the outer loop
-#endif
         double Mx, My, Mz, f[4];
         body_rate(L, pc, qc, rc, wp, wq, wr, Mx, My, Mz);
         allocate(L, thrust_cmd, Mx, My, Mz, f);
         motors(L, f, om, omc);
-#ifdef UAVAC_DIAG_STAMPS
-        const long long dg_s1 = DIAG_NOW();
-        dgc_seg[1] += dg_s1 - dg_s0;                  // body rates, allocation, motors
-#endif
         // late hand-over: slab k-1 goes to the store wave HERE, a third of a tick after it was written -- the barrier's wait for
         // this wave's LDS writes then finds nothing outstanding (the launcher says when that pays)
-#ifdef UAVAC_DIAG_STAMPS
-        if (LOGGING && late_handover && k > 0) { const long long a_ = DIAG_NOW(); lds_barrier(); dgc_wait += DIAG_NOW() - a_; }
-#else
         if (LOGGING && late_handover && k > 0) lds_barrier();
-#endif
 
         double *my = LOGGING ? slab + (size_t)((kk + k) & 1) * NR * NU + tid : nullptr;
         if (LOG_CMD) {
@@ -789,35 +721,17 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
             }
         }
 
-#ifdef UAVAC_DIAG_STAMPS
-        const long long dg_s2 = DIAG_NOW();
-        dgc_seg[2] += dg_s2 - dg_s1;                  // (late barrier,) free-body step
-#endif
         if (LOG_STATE) {
             my[0] = px; my[1 * NU] = py; my[2 * NU] = pz;
             my[3 * NU] = q0; my[4 * NU] = q1; my[5 * NU] = q2; my[6 * NU] = q3;
             my[7 * NU] = vx; my[8 * NU] = vy; my[9 * NU] = vz;
             my[10 * NU] = wp; my[11 * NU] = wq; my[12 * NU] = wr;
         }
-#ifdef UAVAC_DIAG_STAMPS
-        { const long long a_ = DIAG_NOW(); dgc_seg[3] += a_ - dg_s2;  /* the 13 slab writes */
-          if (LOGGING && !late_handover) { lds_barrier(); dgc_wait += DIAG_NOW() - a_; }
-          dgc_last = DIAG_NOW(); }
-#else
         if (LOGGING && !late_handover) lds_barrier();        // hand slab (kk+k)&1 to the store wave; it was drained two ticks ago
-#endif
         ++inner;
         phase = (phase + 1 == V.F) ? 0 : phase + 1;
     }
     if (LOGGING && late_handover && K > 0) lds_barrier();      // the last slab
-#ifdef UAVAC_DIAG_STAMPS
-    if (tid == 0 && blockIdx.x < 8192) {
-        g_uavac_diag[blockIdx.x * 8 + 0] = DIAG_NOW() - dgc_t0; g_uavac_diag[blockIdx.x * 8 + 1] = dgc_wait;
-        g_uavac_diag[blockIdx.x * 8 + 5] = dgc_seg[0]; g_uavac_diag[blockIdx.x * 8 + 6] = dgc_seg[1]; g_uavac_diag[blockIdx.x * 8 + 7] = dgc_seg[2];
-        g_uavac_diag[blockIdx.x * 8 + 2] = dgc_seg[3];      /* (the store wave's barrier time moves out: slot 2 is the slab writes now) */
-        for (int q_ = 0; q_ < 4; ++q_) g_uavac_diag2[blockIdx.x * 4 + q_] = dgc_out[q_];
-    }
-#endif
 
     if (!POLY && nrows > 0) row_wait(nxt);          // nothing may stay in flight into these registers
     if (POLY && ADMA) plan_loads_wait(srows_nx);    // ... nor into this wave's coefficient tile (the next pass, or nobody, owns it)
@@ -922,8 +836,8 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
                        B, K, state_log, cmd_log, aabbs, n_obs, n_tiles, pitch, P, late, n_idle);
     auto tf = [](bool v) { return v ? "true" : "false"; };
     char name[176];
-    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s%s>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
-             tf(GR), tf(YS), PMODE == 1 ? ", 1" : (PMODE == 2 ? ", 2" : ""));
+    snprintf(name, sizeof name, "control_rollout_kernel<%d, %d, %s, %s, %s, %s, %s, %s, %d>", CW, SW, tf(LS), tf(LC), tf(AB), tf(POLY),
+             tf(GR), tf(YS), PMODE);                       // the name rocprofv3 prints, argument for argument
     ctx->last_rollout = name;
     // vector registers of that kernel as the loaded code object has them (once per variant): above 256 a SIMD holds ONE
     // wave of it and the launch runs at 0.65x -- a toolchain that crosses the line shows up here and in bench.py's line

@@ -16,13 +16,6 @@
 #include "minsnap_eval.h"
 #include "minsnap_yaw.h"
 
-#ifdef UAVAC_DIAG_XCD_PERM      // DIAGNOSTIC builds only (tools/scratch/xcd_perm_probe.py): which eighth of the missions each XCD takes
-__device__ int g_diag_xcd_perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-extern "C" int uavac_diag_xcd_perm_one(const int *perm) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xcd_perm), perm, 8 * sizeof(int)) == hipSuccess ? 0 : -3;
-}
-#endif
-
 namespace {
 
 constexpr int SB = 64;                  // rows per chunk == threads per workgroup == one wavefront
@@ -114,13 +107,7 @@ __global__ void __launch_bounds__(SB) minsnap_sample_kernel(const double *__rest
     double *ybuf = reinterpret_cast<double *>(pre + ((m + 2 + 1) & ~1));          // [kYawGroup * SB]
 
     const int lane = threadIdx.x;
-#if defined(UAVAC_DIAG_XCD_PERM)
-    const int b = xcd_contiguous((blockIdx.x & ~7) | g_diag_xcd_perm[blockIdx.x & 7], gridDim.x);
-#elif defined(UAVAC_DIAG_NO_XCD)
-    const int b = blockIdx.x;
-#else
     const int b = xcd_contiguous(blockIdx.x, gridDim.x);      // consecutive missions (consecutive rows in HBM) per XCD
-#endif
     const int64_t row0 = row_offsets[b];
     const int N = (int)(row_offsets[b + 1] - row0);
     if (capacity_rows >= 0 && row_offsets[B] > capacity_rows) {       // uniform over the launch: nobody writes

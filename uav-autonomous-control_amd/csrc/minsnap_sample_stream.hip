@@ -31,21 +31,6 @@
 #include "minsnap_eval.h"
 #include "minsnap_yaw.h"
 
-#ifdef UAVAC_DIAG_STAMPS      // DIAGNOSTIC builds only (tools/sampler_stamps_probe.py): where an item's cycles go, per wave
-__device__ long long g_uavac_sdiag[65536 * 4];      // per workgroup: cycles evaluating / waiting / writing out, items (summed over its waves)
-#define SDIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())
-extern "C" int uavac_sampler_diag_read(long long *out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uavac_sdiag), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -3;
-}
-#endif
-
-#ifdef UAVAC_DIAG_XCD_PERM      // DIAGNOSTIC builds only (tools/scratch/xcd_perm_probe.py): which eighth of the missions each XCD takes
-__device__ int g_diag_xcd_perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-extern "C" int uavac_diag_xcd_perm_stream(const int *perm) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xcd_perm), perm, 8 * sizeof(int)) == hipSuccess ? 0 : -3;
-}
-#endif
-
 namespace {
 
 constexpr int kChunkRows = 64;
@@ -123,13 +108,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
         if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[2], 1);
         return;
     }
-#if defined(UAVAC_DIAG_XCD_PERM)
-    const int wg = xcd_contiguous((blockIdx.x & ~7) | g_diag_xcd_perm[blockIdx.x & 7], gridDim.x);
-#elif defined(UAVAC_DIAG_NO_XCD)
-    const int wg = blockIdx.x;
-#else
     const int wg = xcd_contiguous(blockIdx.x, gridDim.x);                   // consecutive missions (consecutive rows) per XCD
-#endif
     const int b0 = wg * G;
     const int Gn = min(G, B - b0);
 
@@ -171,12 +150,6 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
 
     // ---- items in address order; this wave takes those congruent to w modulo W.  Everything that steers the loops is
     // wave-uniform and kept in scalar registers (readfirstlane: values read from LDS are not uniform to the compiler).
-#ifdef UAVAC_DIAG_STAMPS
-    long long sdg[4] = {0, 0, 0, 0};
-    __shared__ long long sdg_lds[4];
-    if (tid < 4) sdg_lds[tid] = 0;
-    __syncthreads();
-#endif
     int item0 = 0;                                   // workgroup-local index of mission j's first item
     for (int j = 0; j < Gn; ++j) {
         const long long Rj = uniform64(rowoff[j]), Rj1 = uniform64(rowoff[j + 1]);
@@ -196,9 +169,6 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
         const int item0s = __builtin_amdgcn_readfirstlane(item0);
         for (int iv = item0s + ((w - item0s) % W + W) % W; iv < item0s + nitems; iv += W) {   // first item >= item0 congruent to w, ...
             const int i = __builtin_amdgcn_readfirstlane(iv);
-#ifdef UAVAC_DIAG_STAMPS
-            const long long sd0 = SDIAG_NOW();
-#endif
             // (made scalar by hand: the compiler takes them for per-lane values and does the write-out's address arithmetic in vector instructions)
             const long long g0 = uniform64(((kfirst + (i - item0s)) << 6) - phase);   // row (of the batch) in lane 0; may lie before the buffer
             const int rel0 = __builtin_amdgcn_readfirstlane((int)(g0 - Rj));         // the same, counted from the mission's first row
@@ -235,16 +205,12 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
                 }
             }
             const bool valid = active && has_heading(vx, vy);
-#ifdef UAVAC_DIAG_NO_ATAN
-            const double ang = valid ? vy + vx : 0.0;
-#else
             double ang = 0.0;
             if (valid) {
                 HeadingFromLds hc;
                 hc.lds = lds_address(heading_poly);
                 ang = heading_with(vy, vx, hc);
             }
-#endif
             const unsigned long long mask = __ballot(valid);
             const unsigned long long below = (1ull << lane) - 1ull;
             const unsigned long long lower = mask & below;
@@ -260,10 +226,6 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
             bool c_has = false;
             double c_ang = 0.0, c_sum = 0.0, c_first = 0.0;
             // (the hand-over is the one serial piece of a workgroup: it runs ahead of the other waves of its SIMD)
-#ifdef UAVAC_DIAG_STAMPS
-            asm volatile("" : "+v"(corr));
-            const long long sd1 = SDIAG_NOW();
-#endif
             __builtin_amdgcn_s_setprio(2);
             if (i > 0) {
                 const unsigned src = lds_address(&mail[w == 0 ? W - 1 : w - 1]);
@@ -282,9 +244,6 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
                     c_ang = uniform_double(ca); c_sum = uniform_double(cs); c_first = uniform_double(cf);
                 }
             }
-#ifdef UAVAC_DIAG_STAMPS
-            const long long sd2 = SDIAG_NOW();
-#endif
             // np.unwrap's step from the last heading before this item to its first one, then np.cumsum's order, left to right
             // (an item without corrections -- nearly every one -- hands the sum on as it came: the test is all that stands between
             // the carry's arrival and its publication)
@@ -346,21 +305,10 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
                 }
             }
             lds_wave_fence();                     // the staged chunk is in registers / on its way; its stores stay in flight
-#ifdef UAVAC_DIAG_STAMPS
-            {
-                const long long sd3 = SDIAG_NOW();
-                sdg[0] += sd1 - sd0; sdg[1] += sd2 - sd1; sdg[2] += sd3 - sd2; sdg[3] += 1;       // evaluation + staging + headings / wait for the carry / hand-over + yaw + write-out
-            }
-#endif
         }
         item0 += nitems;
     }
 
-#ifdef UAVAC_DIAG_STAMPS
-    if (lane == 0) for (int q_ = 0; q_ < 4; ++q_) atomicAdd((unsigned long long *)&sdg_lds[q_], (unsigned long long)sdg[q_]);
-    __syncthreads();
-    if (tid < 4 && blockIdx.x < 65536) g_uavac_sdiag[blockIdx.x * 4 + tid] = sdg_lds[tid];
-#endif
     // ---- leading rows that were written before their mission's first heading was known
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -248,6 +248,21 @@ int uavac_create(uavac_ctx **out, int device_id) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0)
             ctx->n_simds = 4 * cus;
     }
+    // The rollout's yaw scan (device library atan2) and the sampler's (uavac_yaw::heading) must agree bit for bit, or plan-fed and
+    // row-fed flights part at np.unwrap's forks: checked on this device with this toolchain's library, once per context (~0.1 ms).
+    if (!getenv("UAVAC_SKIP_SELFCHECK")) {
+        int bad = -1;
+        const int rc = uavac_heading_selfcheck(ctx, &bad);
+        if (rc != UAVAC_OK || bad != 0) {
+            if (rc == UAVAC_OK)
+                fprintf(stderr, "libuavac: self-check failed: heading() and the device library's atan2 differ on %d of 65680 operand pairs "
+                                "(built with: %s) -- rebuild against this ROCm\n", bad, uavac_build_info());
+            (void)hipFree(ctx->d_flags);
+            (void)hipStreamDestroy(ctx->own_stream);
+            delete ctx;
+            return rc != UAVAC_OK ? rc : UAVAC_ETOOLCHAIN;
+        }
+    }
     *out = ctx;
     return UAVAC_OK;
 }
@@ -338,6 +353,18 @@ int uavac_last_rollout_vgprs(const uavac_ctx *ctx) { return ctx ? ctx->last_roll
 const char *uavac_build_info(void) {
     return "libuavac " UAVAC_STR(UAVAC_VERSION) "; gfx950; HIP " UAVAC_STR(HIP_VERSION_MAJOR) "." UAVAC_STR(HIP_VERSION_MINOR) "."
            UAVAC_STR(HIP_VERSION_PATCH) "; " __VERSION__;
+}
+
+int uavac_device_identity(uavac_ctx *ctx, char *buf, int n) {
+    UAVAC_ENTER(ctx);
+    if (!buf || n < 1) return uavac_fail(ctx, UAVAC_EINVAL, "null buffer");
+    hipDeviceProp_t prop;
+    UAVAC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    char uuid[33] = {0}, pci[32] = {0};
+    for (int i = 0; i < 16; ++i) snprintf(uuid + 2 * i, 3, "%02x", (unsigned)(unsigned char)prop.uuid.bytes[i]);
+    if (hipDeviceGetPCIBusId(pci, (int)sizeof pci, ctx->device) != hipSuccess) pci[0] = 0;
+    snprintf(buf, (size_t)n, "uuid=%s;pci=%s;name=%s", uuid, pci, prop.gcnArchName);
+    return UAVAC_OK;
 }
 
 int uavac_take_flags(uavac_ctx *ctx, int32_t flags[4]) {

@@ -105,6 +105,10 @@ __device__ __forceinline__ int xcd_contiguous(int block, int n) {
 }
 #endif
 
+// uavac_create's self-check (control_probe.hip): the sampler's heading() against the device library's atan2, which the rollout's
+// yaw scan uses, on 2^16 + 144 operand pairs; *mismatches = pairs whose bits differ.
+int uavac_heading_selfcheck(uavac_ctx *ctx, int *mismatches);
+
 // Device scratch arena (uavac_api.hip).  reserve() makes room for `bytes` in total (synchronises the stream and
 // reallocates when it has to grow) and rewinds the arena; take() hands out 256-byte aligned pieces of it.
 int uavac_arena_reserve(uavac_ctx *ctx, size_t bytes);

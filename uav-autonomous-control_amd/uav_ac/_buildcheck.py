@@ -79,6 +79,99 @@ def check_rollout_registers(obj: str = None):
     return counts
 
 
+def _disassemble(obj: str):
+    """{kernel name: [instruction text]} of the gfx950 code object inside `obj`, or None when it or the LLVM tools are missing."""
+    objdump = os.path.join(LLVM_BIN, "llvm-objdump")
+    if not (os.path.exists(obj) and os.path.exists(objdump)):
+        return None
+    tmp = tempfile.mkdtemp()
+    try:
+        shutil.copy(obj, os.path.join(tmp, "o.o"))
+        subprocess.run([objdump, "--offloading", "o.o"], cwd=tmp, check=True, capture_output=True)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f][0]
+        text = subprocess.run([objdump, "-d", "--no-show-raw-insn", os.path.join(tmp, co)], check=True, capture_output=True,
+                              text=True).stdout
+    finally:
+        shutil.rmtree(tmp)
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        head = re.match(r"[0-9a-f]+ <([^>]+)>:", line)
+        if head:
+            cur = kernels.setdefault(head.group(1), [])
+        elif cur is not None:
+            ins = line.split("//")[0].strip()
+            if ins and not ins.endswith(":"):
+                cur.append(ins)
+    return kernels
+
+
+def _vregs(text: str):
+    regs = set()
+    for lo, hi, one in re.findall(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        regs.update(range(int(lo), int(hi) + 1) if lo else (int(one),))
+    return regs
+
+
+_ROW_LOAD = re.compile(r"global_load_dwordx4 v\[(\d+):(\d+)\], (v\[\d+:\d+\]), off(?: offset:(\d+))?$")
+
+
+def check_row_prefetch(obj: str = None):
+    """The row-fed rollout kernels prefetch a trajectory row with loads the compiler does not know to be in flight (inline asm,
+    control_rollout.hip row_issue / row_wait).  That is only right while the loads land in the very registers row_wait() hands
+    on: for every row-fed variant, (1) every group of five row loads writes the same twenty registers, (2) nothing else writes or
+    reads one of them unless -- walking back through the code -- an `s_waitcnt vmcnt(0)` comes before any row load (code ahead of
+    the first row load is free to use them).  Raises RuntimeError otherwise; returns the number of variants checked, None when
+    the object file cannot be read."""
+    kernels = _disassemble(obj or os.path.join(PKG, "build", "control_rollout.o"))
+    if kernels is None:
+        return None
+    checked, bad = 0, []
+    for name, ins in kernels.items():
+        if "control_rollout_kernel" not in name:
+            continue
+        groups, i = [], 0
+        while i + 4 < len(ins):
+            ms = [_ROW_LOAD.match(x) for x in ins[i:i + 5]]
+            if all(ms) and [int(m.group(4) or 0) for m in ms] == [0, 16, 32, 48, 64] and len({m.group(3) for m in ms}) == 1:
+                groups.append((i, frozenset(r for m in ms for r in range(int(m.group(1)), int(m.group(2)) + 1))))
+                i += 5
+            else:
+                i += 1
+        poly = re.search(r"control_rollout_kernelILi\d+ELi\d+ELb[01]ELb[01]ELb[01]ELb([01])E", name).group(1) == "1"
+        if poly:                                   # (its coefficient loads look alike; the compiler issues and waits for those itself)
+            continue
+        checked += 1
+        if len(groups) != 2 or len({g for _, g in groups}) != 1 or len(groups[0][1]) != 20:
+            bad.append((name[:90], f"row-load groups: {[(i, sorted(g)[:1], len(g)) for i, g in groups]}"))
+            continue
+        dest, inside = groups[0][1], {j for i, _ in groups for j in range(i, i + 5)}
+        for j, x in enumerate(ins):
+            if j in inside or not (_vregs(x) & dest):
+                continue
+            k = j - 1
+            while k >= 0 and k not in inside and not re.match(r"s_waitcnt vmcnt\(0\)", ins[k]):
+                k -= 1
+            if k in inside:
+                bad.append((name[:90], f"'{x}' touches a row register while the row loads may be in flight"))
+                break
+    if bad or checked < 16:
+        raise RuntimeError(f"row prefetch of the row-fed rollout kernels: {checked} variants checked; {bad} (compiler: {compiler_version()})")
+    return checked
+
+
+def check_no_diagnostics(lib_path: str = None):
+    """The shipped library exports no diagnostic entry point (`uavac_diag_*`): those exist only in tools/diag builds."""
+    lib_path = lib_path or os.path.join(PKG, "lib", "libuavac.so")
+    readelf = os.path.join(LLVM_BIN, "llvm-readelf")
+    if not (os.path.exists(lib_path) and os.path.exists(readelf)):
+        return None
+    syms = subprocess.run([readelf, "--dyn-syms", "-W", lib_path], check=True, capture_output=True, text=True).stdout
+    diag = [line.split()[-1] for line in syms.splitlines() if "diag" in line.lower() and " UND " not in line]
+    if diag:
+        raise RuntimeError(f"{lib_path} exports diagnostic symbols {diag}: it was built with a UAVAC_DIAG_* define")
+    return True
+
+
 def compiler_version() -> str:
     try:
         out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True, timeout=60).stdout

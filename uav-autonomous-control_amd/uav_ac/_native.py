@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UAVAC_LIB: another build of the same ABI (development: A/B of two builds on one box, tools/)
 LIB_PATH = os.environ.get("UAVAC_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libuavac.so")
 
-OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM, ETOOLCHAIN = 0, -1, -2, -3, -4, -5, -6, -7
 COMM_ID_BYTES = 128
 MAX_SEGMENTS = 64
 TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 30, 4, 12
@@ -65,6 +65,8 @@ _SIGNATURES = {
     "uavac_device": (C.c_int, [_P]),
     "uavac_last_rollout_kernel": (C.c_char_p, [_P]),
     "uavac_last_rollout_vgprs": (C.c_int, [_P]),
+    "uavac_device_identity": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "uavac_clock_probe_dev": (C.c_int, [_P, C.c_int, _P]),
     "uavac_build_info": (C.c_char_p, []),
     "uavac_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "uavac_take_flags": (C.c_int, [_P, _P]),
@@ -200,6 +202,9 @@ class Context:
         rc = lib().uavac_create(C.byref(self._h), -1 if device is None else int(device))
         if rc != OK:
             self._h = _P()
+            if rc == ETOOLCHAIN:
+                raise UavacError(rc, "uavac_create refused: this build's heading() and the device library's atan2 differ (see stderr); "
+                                     "rebuild libuavac.so against the installed ROCm")
             raise UavacError(rc, "uavac_create failed: no usable MI355X / HIP runtime (there is no CPU fallback)")
         # contexts are destroyed by an atexit hook registered AFTER torch's HIP runtime came up, i.e. run BEFORE its
         # teardown -- not left to __del__ during interpreter shutdown, when the runtime may already be gone
@@ -250,6 +255,12 @@ class Context:
 
     def last_rollout_vgprs(self) -> int:
         return int(lib().uavac_last_rollout_vgprs(self._h))
+
+    def device_identity(self) -> str:
+        """"uuid=...;pci=...;name=..." of the GPU this ctx runs on."""
+        buf = C.create_string_buffer(160)
+        self.call("uavac_device_identity", buf, 160)
+        return buf.value.decode()
 
 
 PILOT_CONTROLLER, PILOT_DYNAMICS = 1, 2

@@ -181,6 +181,23 @@ class Engine:
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
 
+    def clock_probe_begin(self, window_us: int, stream=None):
+        """Start ONE wavefront on `stream` (a side stream: it then runs BESIDE whatever the current stream executes) that stamps
+        shader cycles and real time `window_us` apart (`uavac_clock_probe_dev`).  Returns the ticket for `clock_probe_ghz`."""
+        torch = self._torch
+        stamps = torch.zeros((4,), dtype=torch.int64, device=self.device)
+        with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
+            self._bind_stream()
+            self.ctx.call("uavac_clock_probe_dev", int(window_us), _ptr(stamps))
+        self._bind_stream()                                   # back on the caller's stream
+        return stamps
+
+    @staticmethod
+    def clock_probe_ghz(stamps) -> float:
+        """Shader clock over a finished probe's window: (cycles1 - cycles0) / (real1 - real0) x 100 MHz.  (Synchronises.)"""
+        c0, r0, c1, r1 = (int(v) for v in stamps.cpu().tolist())
+        return (c1 - c0) / max(1, r1 - r0) * 0.1
+
     # -- planning ---------------------------------------------------------------
     def plan(self, waypoints, velocity: float = 1.0, dt: float = 0.01, strict: bool = True, dense_yaw: bool = False,
              placement_trials: int = 1, pool: bool = False) -> Plan:
@@ -801,9 +818,10 @@ class Fleet:
         """K fused ticks.  state_log / cmd_log: None, True (allocate) or a preallocated tensor.
 
         Layout of the logs: rows are `pitch` doubles apart, [K][13 | 12][pitch], columns B .. pitch-1 never touched.
-        * A caller's tensor is written DENSELY ([K][rows][B] in its first K*rows*B elements, whatever its shape) unless
-          `log_pitch` says otherwise -- then it must hold K*rows*log_pitch elements (log_pitch >= B).  The pitch is never
-          inferred from a tensor's shape.
+        * A caller's tensor is written DENSELY ([K][rows][B] in its first K*rows*B elements) unless `log_pitch` says
+          otherwise -- then it must hold K*rows*log_pitch elements (log_pitch >= B).  The pitch is never inferred from a
+          tensor's shape, and a 3-D tensor whose last dimension is not the pitch that will be written is REFUSED (ValueError):
+          indexing it as (K, rows, P) afterwards would read scrambled data.
         * A log allocated here (True) takes the pitch of the caller's other log, else `log_pitch`, else B rounded up to a
           multiple of 16 (rows on 128-byte lines: B = 65 534 at pitch B streams at half the rate of 65 536).
         Returns (state_log, cmd_log) as (K, rows, B) views of pitched buffers (the tensor itself for a caller's dense one), or
@@ -826,10 +844,13 @@ class Fleet:
                 t = torch.empty((K, rows, pitch), dtype=torch.float64, device=e.device)
             elif t.dtype != torch.float64 or not t.is_contiguous() or t.numel() < K * rows * pitch:
                 raise ValueError(f"{name} must be a contiguous float64 tensor with >= K*{rows}*{pitch} elements")
+            elif t.dim() == 3 and t.shape[2] != pitch:
+                raise ValueError(f"{name} has rows of {t.shape[2]} doubles but would be written with rows of {pitch}: pass "
+                                 f"log_pitch={t.shape[2]} (or a tensor whose last dimension is {pitch})")
             bufs[name] = t
             dense_callers = pitch == B and (state_log if name == "state_log" else cmd_log) is not True
             views[name] = t if dense_callers else t.reshape(-1)[:K * rows * pitch].view(K, rows, pitch)[:, :, :B]
-        pitched = pitch != B
+        pitched = pitch != B and bool(bufs)                  # (an unlogged rollout has no pitch to set)
         if pitched:
             e.ctx.set_option("log_pitch", pitch)
         try:
@@ -931,33 +952,82 @@ def shard_bounds(B: int, rank: int, world: int, root_share: float = None, root: 
     return lo, lo + sizes[rank]
 
 
-# One MI355X, measured (profiles/NOTES.md A1, r03_config_sweep): time of one logged tick by batch size, us
-_TICK_US = ((4096, 0.76), (16384, 0.766), (24576, 0.842), (32768, 0.871), (49152, 1.0), (65536, 1.25))
+# One MI355X, measured (round 4: profiles/r04_config_sweep.jsonl, tools/rollout_ab.py, m = 8 .. 12): UAVs in flight on the GPU,
+# us per logged tick, ms of the planning chain per 1 000 missions.  A FALLBACK: `measure_tick_table` measures the same three
+# columns on the GPU at hand in a few tens of milliseconds, and `bench.py --gpus N` does so before it cuts the shards.
+DEFAULT_TICK_TABLE = ((4096, 0.753, 0.028), (16384, 0.792, 0.0180), (24576, 0.86, 0.0178), (32768, 0.885, 0.0177), (49152, 1.02, 0.0176),
+                      (65536, 1.28, 0.0176))
+
+
+def measure_tick_table(engine: "Engine", segments: int, sizes, velocity: float = 3.0, dt: float = 0.01, ticks: int = 500,
+                       launches: int = 3, seed: int = 7):
+    """What a shard of n missions costs on THIS GPU, for every n in `sizes`: [(n, us per logged tick, ms of the planning chain
+    per 1 000 missions)].  Synthetic missions of the SURVEY 8(d) shape, planned once more after a warm-up, then `launches`
+    logged launches of `ticks` ticks (the first is thrown away).  A few tens of milliseconds per size."""
+    torch = engine._torch
+    rng = np.random.default_rng(seed)
+    table = []
+    for n in sorted({int(x) for x in sizes if int(x) > 0}):
+        d = rng.standard_normal((n, segments, 3)) * np.array([1, 1, 0.25])
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        w0 = np.concatenate([rng.uniform(0, 24, (n, 1, 1)), rng.uniform(0, 14, (n, 1, 1)), np.full((n, 1, 1), -3.0)], axis=2)
+        wps = np.concatenate([w0, w0 + np.cumsum(rng.uniform(2.5, 3.5, (n, segments, 1)) * d, axis=1)], axis=1)
+        plan = engine.plan(wps, velocity, dt)
+        fleet = engine.fleet(plan)
+        pitch = -(-n // 16) * 16
+        log = torch.empty((ticks, 13, pitch), dtype=torch.float64, device=engine.device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        engine.replan(plan)
+        ev[0].record()
+        engine.replan(plan)
+        ev[1].record()
+        fleet.reset()
+        fleet.rollout(ticks, state_log=log, log_pitch=pitch)
+        ev[2].record()
+        for _ in range(launches - 1):
+            fleet.rollout(ticks, state_log=log, log_pitch=pitch)
+        ev[3].record()
+        torch.cuda.synchronize(engine.device)
+        table.append((n, ev[2].elapsed_time(ev[3]) * 1e3 / ((launches - 1) * ticks), ev[0].elapsed_time(ev[1]) / (n / 1000.0)))
+        del plan, fleet, log
+    return table
+
+
+def candidate_shard_sizes(B: int, world: int):
+    """The shard sizes worth measuring before `balanced_root_share` cuts a B-mission job over `world` ranks: half an equal block
+    (about what the root ends up with), an equal block, and a peer's block when the root takes next to nothing."""
+    eq = max(1, B // world)
+    return sorted({max(1, eq // 2), eq, min(B, -(-B // max(1, world - 1)))})
 
 
 def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_segment: float = 112.9,
-                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 5.8e12) -> float:
+                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 5.8e12, tick_table=None) -> float:
     """The share of a B-mission job the gather's root should take so that it finishes with its peers (BASELINE configs[3]).
 
-    A PROJECTION from one-GPU measurements on MI355X, not a measurement of N GPUs: a peer with n missions plans them
-    (sampler-bound, 88 B per row at ~5.3 TB/s) and flies `ticks` logged ticks (`_TICK_US`, linear above 65 536 UAVs); the
-    root does the same for its own block and, beside it, receives the peers' plans and re-samples their rows (plan gather)
-    or receives the rows themselves -- either way its HBM takes the peers' rows on top of its own log (104 B per UAV
-    tick), so its time is the larger of its flight and of (log + all rows) / the HBM write rate.  Bisection on the share."""
+    A PROJECTION from one-GPU measurements, not a measurement of N GPUs: a peer with n missions plans them and flies `ticks`
+    logged ticks -- both read off `tick_table` = [(n, us per logged tick, ms of planning per 1 000 missions)], as
+    `measure_tick_table` returns it for the GPU at hand (default: `DEFAULT_TICK_TABLE`, round-4 numbers of one MI355X), linear
+    between its points, flat below the first, proportional to n above the last; the root does the same for its own block and,
+    beside it, receives the peers' plans and re-samples their rows (plan gather) or receives the rows themselves -- either way
+    its HBM takes the peers' rows on top of its own log (104 B per UAV tick), so its time is the larger of its flight and of
+    (log + all rows) / the HBM write rate.  Bisection on the share."""
     if world <= 1:
         return 1.0
+    table = sorted((float(n), float(t), float(p)) for n, t, p in (tick_table or DEFAULT_TICK_TABLE))
+    if not table or any(t <= 0 or p <= 0 or n <= 0 for n, t, p in table):
+        raise ValueError("tick_table: [(missions, us per tick, ms of planning per 1000 missions)], all positive")
     row_bytes = 88.0 * rows_per_segment * segments                       # per mission
 
-    def tick_us(n):
-        if n <= _TICK_US[0][0]:
-            return _TICK_US[0][1]
-        for (n0, t0), (n1, t1) in zip(_TICK_US, _TICK_US[1:]):
-            if n <= n1:
-                return t0 + (t1 - t0) * (n - n0) / (n1 - n0)
-        return _TICK_US[-1][1] * n / _TICK_US[-1][0]
+    def lookup(n, col):
+        if n <= table[0][0]:
+            return table[0][col]
+        for lo_, hi_ in zip(table, table[1:]):
+            if n <= hi_[0]:
+                return lo_[col] + (hi_[col] - lo_[col]) * (n - lo_[0]) / (hi_[0] - lo_[0])
+        return table[-1][col] * (n / table[-1][0] if col == 1 else 1.0)   # a full chip walks its tiles pass after pass
 
     def own(n):                                                          # plan + flight of n missions, seconds
-        return n * row_bytes / 5.3e12 + ticks * tick_us(n) * 1e-6
+        return lookup(n, 2) * 1e-3 * n / 1000.0 + ticks * lookup(n, 1) * 1e-6
 
     def root_time(s):
         n = s * B
@@ -1013,6 +1083,12 @@ class RcclComm:
         engine._bind_stream()
         engine.ctx.call("uavac_comm_init_rank", C.create_string_buffer(unique_id, nat.COMM_ID_BYTES), self.world, self.rank,
                         C.byref(self._h))
+
+    def shape(self):
+        """(ranks, this rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        w, r = C.c_int(-1), C.c_int(-1)
+        self.engine.ctx.call("uavac_comm_shape", self._h, C.byref(w), C.byref(r))
+        return int(w.value), int(r.value)
 
     def counts(self, n_rows: int):
         out = (C.c_int64 * self.world)()
