@@ -502,31 +502,31 @@ def main():
             sampler_ms[label] = round(a.elapsed_time(b) / 5, 4)
         eng.ctx.set_option("sampler_waves", 4)
         # The same steps once more with the shader clock beside them: one extra wavefront on a side stream stamps s_memtime /
-        # s_memrealtime over the first millisecond of every planning chain and over 10 ms of the flight behind it
-        # (uavac_clock_probe_dev).  Untimed; the steps `value` was measured on carry no probe.  `ms_median` of this leg against
-        # the timed leg's is the instrument's leg-to-leg repeatability on one row buffer.
+        # s_memrealtime over a millisecond of every planning chain (uavac_clock_probe_dev; it starts a few tens of microseconds
+        # into the chain, when the host gets to it).  Untimed: the steps `value` was measured on carry no probe.  Enqueued like
+        # the timed steps -- back to back, nothing synchronises in between -- so `ms_median` of this leg against the timed leg's is
+        # the instrument's leg-to-leg repeatability on one row buffer.  (No probe beside the ROLLOUT of a full chip: its workgroups
+        # fill every SIMD's registers to the last one, and the workgroup whose SIMD the probe's wave holds starts a probe late.)
         side = torch.cuda.Stream(device=dev)
-        clocked = {"planning_ms": [], "planning_clock_ghz": [], "rollout_ms_per_launch": [], "rollout_clock_ghz": []}
+        clocked = {"planning_ms": [], "planning_clock_ghz": []}
         try:
+            marks = []
             for i in range(10):
-                e0, e1, e2 = ev(), ev(), ev()
+                e0, e1 = ev(), ev()
                 e0.record()
-                side.wait_event(e0)
-                p_plan = eng.clock_probe_begin(1000, stream=side)
                 eng.replan(plan)
                 e1.record()
-                side.wait_event(e1)
-                p_roll = eng.clock_probe_begin(10000, stream=side)
+                side.wait_event(e0)
+                probe = eng.clock_probe_begin(1000, stream=side)
                 fleet.reset()
                 for _ in range(n_chunks):
                     fleet.rollout(CHUNK, state_log=log)
-                e2.record()
-                torch.cuda.synchronize()
-                if i >= 2:
-                    clocked["planning_ms"].append(round(e0.elapsed_time(e1), 4))
-                    clocked["rollout_ms_per_launch"].append(round(e1.elapsed_time(e2) / n_chunks, 4))
-                    clocked["planning_clock_ghz"].append(round(eng.clock_probe_ghz(p_plan), 3))
-                    clocked["rollout_clock_ghz"].append(round(eng.clock_probe_ghz(p_roll), 3))
+                torch.cuda.current_stream(dev).wait_stream(side)          # the next step's planning starts behind this probe's end
+                marks.append((e0, e1, probe))
+            torch.cuda.synchronize()
+            for e0, e1, probe in marks[2:]:
+                clocked["planning_ms"].append(round(e0.elapsed_time(e1), 4))
+                clocked["planning_clock_ghz"].append(round(eng.clock_probe_ghz(probe), 3))
             clocked["ms_median"] = float(np.median(clocked["planning_ms"]))
             clocked["clock_ghz"] = float(np.median(clocked["planning_clock_ghz"]))
         except Exception as exc:                              # an extra: the line's measurements above must survive it
@@ -552,7 +552,6 @@ def main():
             if "clock_ghz" in clocked:
                 out["minsnap"]["clock_ghz"] = clocked["clock_ghz"]
                 out["minsnap"]["leg_to_leg"] = clocked["ms_median"] / out["minsnap"]["ms_median"]
-                out["roofline"]["clock_ghz"] = float(np.median(clocked["rollout_clock_ghz"]))
             out["rollout_only_flyable"] = {"value": B * CHUNK * n_chunks / (a.elapsed_time(b) * 1e-3),
                                            "unit": "UAV control-steps/s per GPU", "velocity": VELOCITY / 2,
                                            "frac_uavs_within_0.5m_of_target_row": kept2,

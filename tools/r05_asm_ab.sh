@@ -4,8 +4,8 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/r05_asm_ab.jsonl
 : > $OUT
-for spec in ${@:-"4096 rows" "8192 rows" "16384 rows" "4096 plan" "16384 plan" "32768 plan" "49152 plan" "65536 plan"}; do
-  set -- $spec
-  python3 tools/rollout_ab.py tools/ab/libuavac_r04.so $1 $2 2>/dev/null | grep '^{' >> $OUT
+if [ $# -eq 0 ]; then set -- "4096 rows" "8192 rows" "16384 rows" "4096 plan" "16384 plan" "32768 plan" "49152 plan" "65536 plan"; fi
+for spec in "$@"; do
+  python3 tools/rollout_ab.py tools/ab/libuavac_r04.so $spec 2>/dev/null | grep '^{' >> $OUT
 done
 cat $OUT

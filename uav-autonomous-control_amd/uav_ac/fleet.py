@@ -185,8 +185,8 @@ class Engine:
         """Start ONE wavefront on `stream` (a side stream: it then runs BESIDE whatever the current stream executes) that stamps
         shader cycles and real time `window_us` apart (`uavac_clock_probe_dev`).  Returns the ticket for `clock_probe_ghz`."""
         torch = self._torch
-        stamps = torch.zeros((4,), dtype=torch.int64, device=self.device)
         with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
+            stamps = torch.empty((4,), dtype=torch.int64, device=self.device)      # (the kernel writes all four; no fill on another stream)
             self._bind_stream()
             self.ctx.call("uavac_clock_probe_dev", int(window_us), _ptr(stamps))
         self._bind_stream()                                   # back on the caller's stream
