@@ -186,11 +186,17 @@ def test_pitched_logs_equal_dense_logs_and_leave_the_padding_alone(eng, B):
     s2, c2 = f2.rollout(K, state_log=True, cmd_log=True)
     assert s2.shape == (K, 13, B) and s2.stride(1) % 16 == 0
     assert torch.equal(s2, dense_s) and torch.equal(c2, dense_c)
-    # round-3 ADVICE: a caller's tensor is written densely whatever its shape (the pitch is never inferred from it), ...
+    # round-3 ADVICE: the pitch is never inferred from a caller's tensor -- a flat buffer is written densely; round-4 ADVICE: a 3-D
+    # tensor whose rows are NOT the pitch that will be written is refused (indexing it as (K, 13, P) afterwards would read
+    # scrambled data without any error), ...
     f3 = eng.fleet(plan, from_plan=False)
     wide = torch.full((K, 13, P), -5.0, dtype=torch.float64, device=eng.device)
-    f3.rollout(K, state_log=wide)
-    assert torch.equal(wide.reshape(-1)[:K * 13 * B].view(K, 13, B), dense_s) and bool((wide.reshape(-1)[K * 13 * B:] == -5.0).all())
+    with pytest.raises(ValueError, match="log_pitch"):
+        f3.rollout(K, state_log=wide)
+    assert bool((wide == -5.0).all())                                  # refused before anything was launched
+    flat = wide.reshape(-1)
+    got, _ = f3.rollout(K, state_log=flat)
+    assert got is flat and torch.equal(flat[:K * 13 * B].view(K, 13, B), dense_s) and bool((flat[K * 13 * B:] == -5.0).all())
     # ... a log allocated beside a caller's dense one takes the same pitch instead of being refused (B % 16 != 0 too), ...
     f4 = eng.fleet(plan, from_plan=False)
     mine = torch.empty((K, 12, B), dtype=torch.float64, device=eng.device)
@@ -500,8 +506,9 @@ def test_host_pointer_obstacle_loop_equals_the_engine(eng, nat):
 
 def test_bench_line_schema_with_extras():
     """`python bench.py` as the driver runs it (fewer steps): ONE JSON line with the contract's keys, `roofline` and `minsnap` priced
-    both by algorithmic and by counter bytes when profiles/hbm_traffic.json matches the sources, the first allocation's planning
-    rate next to the searched-once leg (two row buffers alive at most), per-launch times, exit code 0."""
+    both by algorithmic and by counter bytes when profiles/hbm_traffic.json matches the sources, the planning chain as median and
+    spread over the timed steps with the shader clock of a second, probed leg beside it (round-4 VERDICT 4: no placement search in
+    the driver's bench any more), per-launch times, exit code 0."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -520,9 +527,11 @@ def test_bench_line_schema_with_extras():
     assert len(rf["per_launch_ms_one_step"]) == 10 and rf["kernel_vgprs"] <= 256
     m = d["minsnap"]
     assert 0.45 < m["frac_first_allocation"] < 0.85 and m["roofline"]["frac"] == m["frac_first_allocation"]
-    once = m["row_buffer_searched_once"]
-    assert once["row_buffers_alive_at_most"] == 2 and 1 <= len(once["sampler_ms_per_draw"]) <= 24 and 0.45 < once["frac"] < 0.85
-    assert once["frac"] >= m["frac_first_allocation"] - 0.03            # a search never ends on a clearly worse buffer than it began with
+    assert "row_buffer_searched_once" not in m
+    assert m["ms_min"] <= m["ms_median"] <= m["ms_max"] and len(m["ms_per_timed_step"]) == 3 and 0.45 < m["frac_median"] < 0.85
+    ck = m["clocked_steps"]
+    assert "error" not in ck and len(ck["planning_ms"]) == 8 and all(1.0 < g < 2.6 for g in ck["planning_clock_ghz"])
+    assert m["clock_ghz"] == ck["clock_ghz"] and 0.9 < m["leg_to_leg"] < 1.1
     if rf["traffic"] is not None:                                        # profiles/hbm_traffic.json was measured on these sources
         assert 0.85 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.05 and rf["frac_counter_bytes"] < rf["frac"]
 

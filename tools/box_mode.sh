@@ -21,6 +21,3 @@ PY
 sleep 4
 rocm-smi --showclocks --showpower --showperflevel 2>/dev/null | grep -v "^=\|^$" | head -30
 wait
-export TMPDIR=/tmp
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_clock -o pmc -- python3 tools/sampler_clock.py > /dev/null 2>&1
-python3 tools/sampler_clock.py --report gpurun_out/pmc_clock

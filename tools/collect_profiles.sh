@@ -34,6 +34,7 @@ for r in csv.DictReader(open(f)):
 json.dump({k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in acc.items()}, open(f"{out}/{tag}_small_batch_pmc.json", "w"), indent=1)
 PY
 # 6. issue / exchange micro-probes and the host-facing paths
+[ -x tools/dpp_exchange_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/dpp_exchange_probe.hip -o tools/dpp_exchange_probe.bin
 ./tools/dpp_exchange_probe.bin > "$OUT/${TAG}_dpp_exchange_probe.txt" 2>&1
 python3 tools/single_uav_loop.py 2>/dev/null | tail -4 > "$OUT/${TAG}_single_uav_loop.txt"
 python3 tools/host_path_rate.py 2>/dev/null | tail -2 > "$OUT/${TAG}_host_path_rate.txt"

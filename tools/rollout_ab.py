@@ -32,6 +32,10 @@ for name, lib in libs.items():
     assert lib.uavac_create(C.byref(h), 0) == 0
     assert lib.uavac_set_stream(h, _P(torch.cuda.current_stream().cuda_stream or None)) == 0
     ctxs[name] = h
+    lib.uavac_set_option.argtypes = [_P, C.c_char_p, C.c_int]
+    for opt in ("late_handover", "idle_waves", "coeff_dma"):          # AB_LATE_HANDOVER=1 ...: the same launch option in both libraries
+        if os.environ.get("AB_" + opt.upper()) is not None:
+            assert lib.uavac_set_option(h, opt.encode(), int(os.environ["AB_" + opt.upper()])) == 0
 p = lambda t: _P(t.data_ptr())   # noqa: E731
 kw = dict(device="cuda:0")
 wp = torch.as_tensor(missions(B, m, 0, B), dtype=torch.float64).to("cuda:0").contiguous()

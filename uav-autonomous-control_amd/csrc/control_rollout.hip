@@ -823,12 +823,14 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     const int max_wgs = ctx->n_simds / CW;                     // one compute wave per SIMD at most
     const int grid = (LOGGING && n_tiles > max_wgs) ? max_wgs : n_tiles;
     const int cols = grid * NU < B ? grid * NU : B;            // columns in flight at a time
-    // Hand the slab over at the end of the tick, or a third of a tick later (after the next tick's motor model)?  Results
-    // are the same bit for bit; per 1 000 logged ticks, end-of-tick / late: 0.905 / 0.880 ms at 8 192 and 16 384 columns,
-    // 0.979 / 0.985 at 24 576, 0.996 / 1.044 at 32 768, 1.16 / 1.11-1.14 at 49 152, 1.33 / 1.30 at 65 536 (MI355X: 1 024 SIMDs;
-    // the thresholds scale with the SIMD count of the device).
-    const int late = ctx->late_handover >= 0 ? ctx->late_handover
-                                             : ((cols > 20 * ctx->n_simds && cols < 40 * ctx->n_simds) ? 0 : 1);
+    // Hand the slab over at the end of the tick, or a third of a tick later (after the next tick's motor model)?  Results are the
+    // same bit for bit.  Round 5 (tools/half_chip_options.py, profiles/r05_launcher_sweep_m*.jsonl: every size from 12 288 to
+    // 65 536 UAVs x hand-over point x PMODE, interleaved): the late hand-over wins or ties at EVERY size with the round-4
+    // kernels -- 0.857 against 0.890 ms per 1 000 logged ticks at 32 768 UAVs, 0.852 / 0.883 at 24 576, 1.092 / 1.105 at 57 344 --
+    // so it is the default (round 3 had found a window from 20 480 to 40 960 UAVs where the end of the tick was better; that was
+    // before the target rows left the compute wave's outer tick).  Option "late_handover" still forces either.
+    const int late = ctx->late_handover >= 0 ? ctx->late_handover : 1;
+    (void)cols;
     const size_t pitch = (LS || LC) ? (ctx->log_pitch > 0 ? (size_t)ctx->log_pitch : (size_t)B) : (size_t)B;
     if (LOGGING && ctx->rollout_align)
         hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(threads), 0, ctx->stream);
@@ -872,7 +874,9 @@ void launch_variant(uavac_ctx *ctx, const VehK &V, const double *traj, const int
     int mode = 0;
     if (plan) {
         if (ctx->coeff_dma >= 0) mode = ctx->coeff_dma > 2 ? 2 : ctx->coeff_dma;
-        else mode = in_flight * 64 >= 60 * ctx->n_simds ? 0 : (2 * in_flight <= ctx->n_simds ? 2 : 1);
+        // (round 5, same sweep: the second wave's rows pay up to 26 624 UAVs -- 0.840 against 0.852 ms at 24 576 -- and lose from
+        // 28 672 on -- 0.866 against 0.857 at 32 768: the crossover lies below "two workgroups on every CU")
+        else mode = in_flight * 64 >= 60 * ctx->n_simds ? 0 : (in_flight * 64 <= 26 * ctx->n_simds ? 2 : 1);
         if (mode == 2 && (!LOGGING || V.F < 7)) mode = 1;
     }
 #define UAVAC_LAUNCH_MODE(GR_, YS_)                                                                     \
