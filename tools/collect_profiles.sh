@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, collected on the GPU box into gpurun_out/profiles_<tag>/ (copy what is to be
-# judged into profiles/ afterwards).   bash tools/collect_profiles.sh r04
+# judged into profiles/ afterwards).   bash tools/collect_profiles.sh r05
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 export UAVAC_PROFILE_TAG=$TAG
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/profiles_$TAG
@@ -46,5 +46,12 @@ python3 tools/replan_rate.py 4096 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_re
 # 8. round 4: the two sampler kernels on six row buffers side by side; plan-fed against row-fed rollout by batch size
 python3 tools/sampler_stream_ab.py 8 65536 12 1x1,4x1,2x1,8x1,4x2 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_sampler_stream_ab.jsonl"
 python3 tools/plan_vs_rows.py 2>/dev/null | grep "B=" > "$OUT/${TAG}_plan_vs_rows.txt"
+python3 tools/solve_time.py 2>/dev/null | grep "B=" > "$OUT/${TAG}_solve_park.txt"
+# 9. round 5: the tick below a full chip from the un-instrumented build (time + in-kernel clock per batch size, three counter passes),
+#    the launcher's options over batch size, config 4's 5 000 ticks as five launches and as one
+bash tools/collect_tick_budget.sh "$TAG" > /dev/null 2>&1
+cp gpurun_out/tick_budget_$TAG/*.jsonl "$OUT/" 2>/dev/null
+SWEEP=launcher python3 tools/half_chip_options.py 8 16384 24576 32768 35237 49152 2>/dev/null | grep "^{" > "$OUT/${TAG}_launcher_options_m8.jsonl"
+python3 tools/config4_chunking.py 32768 2>/dev/null | grep "^{" > "$OUT/${TAG}_config4_chunking.jsonl"
 rm -rf "$OUT/trace/"*results.db "$OUT/pmc_small" "$OUT/pmc_rclock"
 ls -la "$OUT"

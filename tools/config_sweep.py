@@ -27,7 +27,16 @@ for name, B, m, K, aabb in (("config2", 4096, 8, 10000, None), ("config3", 65536
     tr = t(roll)
     print(json.dumps({"config": name, "B": B, "m": m, "ticks": K, "rows": plan.total_rows, "plan_ms": tp, "rollout_ms": tr,
                       "steps_per_s": B * K / (tr * 1e-3), "segments_per_s": B * m / (tp * 1e-3),
-                      "collided": int(fleet.collided.sum()) if aabb is not None else None}))
+                      "collided": int(fleet.collided.sum()) if aabb is not None else None, "rollout_kernel": eng.ctx.last_rollout_kernel()}))
+    if name == "config4/8":                  # the same 5 000 ticks as ONE launch into a 17 GB log (round 5: a launch boundary costs ~50 us here)
+        pitch = -(-B // 16) * 16
+        whole = torch.empty((K, 13, pitch), dtype=torch.float64, device="cuda:0")
+        def roll_one():
+            fleet.reset()
+            fleet.rollout(K, state_log=whole, log_pitch=pitch)
+        t1 = t(roll_one)
+        print(json.dumps({"config": name + " as one launch", "B": B, "m": m, "ticks": K, "rollout_ms": t1, "steps_per_s": B * K / (t1 * 1e-3)}))
+        del whole
     if aabb is not None:                     # the same flight without a log: the obstacle test runs in the compute wave
         def roll_nolog(ab):
             fleet.reset()

@@ -45,22 +45,23 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // flight across ticks makes it put `s_waitcnt vmcnt(0)` at every join of the tick loop (its registers are
 // loop-carried).  Issued from inline asm the load is invisible to that pass; the registers are touched by
 // nothing until row_wait(), which every later read is data-dependent on.
-// The operands are "+v": the loads land IN the loop-carried registers.  (An output-only operand may be given a register of its own and
-// copied into the carried one right away, before the data has arrived -- it happened once, NOTES R4-4.)  uav_ac/_buildcheck.py
-// disassembles every row-fed variant and fails the build when anything but these loads writes the destination registers or anything
-// reads them other than behind row_wait()'s s_waitcnt.
+// The operands are output-only ("=&v").  What makes that right is not the constraint but the BUILD CHECK: uav_ac/_buildcheck.py
+// (run by __graft_entry__.build() and by the CPU tests) disassembles every row-fed variant and fails the build unless both issue
+// sites load into the same twenty registers and no instruction reads or writes one of them between the loads and an
+// `s_waitcnt vmcnt(0)` -- i.e. unless the loads land in the very registers row_wait() hands on.  (An output-only operand MAY be
+// given a register of its own and copied into the carried one before the data has arrived; it happened once, NOTES R4-4, and
+// the check is what catches it.  The "+v" form, which ties the destination to the carried register by construction, was measured
+// in round 5: +1.5 % on every row-fed tick -- the twenty registers then stay live through the outer block -- and +2.7 % with an
+// empty block in front to end their live range, tools/r05_asm_ab.sh; so the check carries the guarantee instead.)
 struct RowRegs { u32x4 q[5]; };          // columns 0..9 of a row (x y z vx vy vz ax ay az yaw): 80 bytes
 
 __device__ __forceinline__ void row_issue(RowRegs &r, const double *p) {
-    // (the row consumed last is dead from here on: an empty block "defines" the five register groups anew, so that they are
-    // not kept alive -- as inputs of the loads below -- through the outer block that has just used them: 1.5 % of a row-fed tick)
-    asm volatile("" : "=v"(r.q[0]), "=v"(r.q[1]), "=v"(r.q[2]), "=v"(r.q[3]), "=v"(r.q[4]));
     asm volatile("global_load_dwordx4 %0, %5, off\n\t"
                  "global_load_dwordx4 %1, %5, off offset:16\n\t"
                  "global_load_dwordx4 %2, %5, off offset:32\n\t"
                  "global_load_dwordx4 %3, %5, off offset:48\n\t"
                  "global_load_dwordx4 %4, %5, off offset:64"
-                 : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]), "+v"(r.q[4])
+                 : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.q[3]), "=&v"(r.q[4])
                  : "v"(p)
                  : "memory");
 }
@@ -73,7 +74,7 @@ template <class T> __device__ __forceinline__ void settle(T &x) { asm volatile("
 // LDS tile (LDS-DMA, global_load_lds_dwordx4: no registers, nothing to wait for here) -- issued when the cursor enters the
 // segment, needed one outer tick (F ticks) later.  Loaded through registers on the spot they cost the whole load latency at
 // every segment change of any lane of the wave (44 % of the outer ticks), and that latency grows with the chip's load: 1.1 k
-// cycles at 8 192 UAVs, 2.3 k at 32 768, 3 k at 49 152 (tools/tick_stamps_probe.py) -- it was the half-full chip's longer tick.
+// cycles at 8 192 UAVs, 2.3 k at 32 768, 3 k at 49 152 (NOTES R4-3, profiles/r04_tick_stamps_*.jsonl) -- it was the half-full chip's longer tick.
 // Tile layout [12][64][2] doubles (minsnap_eval.h, STRIDE 0): instruction p moves doubles 2p, 2p + 1 of every active lane; lane l
 // lands at M0 + offset + 16 l, and the instruction offset counts for the GLOBAL address and for the LDS address alike, so M0
 // advances by 1024 - 16 per instruction.  Masked-off lanes keep their column (tools/scratch/ldsdma_gather_probe.hip).
@@ -780,7 +781,7 @@ __global__ void state_init_kernel(const VehK V, const double *__restrict__ posit
 // Empty kernel with the workgroup shape of the logged rollout (two waves).  Where the dispatcher puts the waves of a
 // 2-wave workgroup depends on the shape of the kernel that ran before: after the planning kernels (1-wave
 // workgroups) 5-15 % of the SIMDs receive two compute waves and others two store waves, and the launch runs 25 %
-// slower (tools/first_launch_bisect.py, tools/placement_after_sampler.py; it heals by itself over the next two
+// slower (tools/first_launch_bisect.py, profiles/r02_placement_census.txt; it heals by itself over the next two
 // launches).  After ANY kernel of 2-wave workgroups the placement is one compute + one store wave on every SIMD.
 __global__ void __launch_bounds__(256) rollout_align_kernel() {}
 
