@@ -537,7 +537,7 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
 
     constexpr bool BOX_HERE = AABB && !((LOG_STATE || WATCH) && CW == SW);
 
-    RowRegs nxt = {};
+    RowRegs nxt;
     if (!POLY && nrows > 0) row_issue(nxt, rows + (size_t)min(max(idx, 0), nrows - 1) * UAVAC_TRAJ_COLS);
 
     // POLY: segment / row-in-segment of the cursor, the segment's coefficients and the next 16 yaws, in LDS
