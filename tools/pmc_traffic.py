@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 from bench import B_PER_GPU, CHUNK, F, planning_source_sha, rollout_source_sha  # noqa: E402
 
 OUT = os.path.join(ROOT, "gpurun_out")
-TAG = os.environ.get("UAVAC_PROFILE_TAG", "r04")          # round tag of the files written
+TAG = os.environ.get("UAVAC_PROFILE_TAG", "r05")          # round tag of the files written
 KERNELS = {"control_rollout": "control_rollout_kernel", "minsnap_sample": "minsnap_sample_stream_kernel",
            "minsnap_solve": "minsnap_solve_bt_kernel"}
 
@@ -52,10 +52,7 @@ def collect(counter):
                     big = int(r["Grid_Size"]) >= B_PER_GPU
                     if big:
                         name = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0]
-                        # the library names a rollout variant by its first eight template arguments and appends the ninth
-                        # (who evaluates target rows / how coefficients arrive) only when it is not 0: the same here
-                        if key == "control_rollout" and name.endswith(", 0>") and name.count(",") == 8:
-                            name = name[:-len(", 0>")] + ">"
+                        # (the library reports the launched variant under the very name rocprofv3 prints, all nine arguments)
                         per.setdefault((key, name), []).append(float(r["Counter_Value"]))
     return per
 
