@@ -128,6 +128,10 @@ int uavac_clock_probe_dev(uavac_ctx *ctx, int window_us, int64_t *stamps);
  * many 64-row chunks of the sampler's dense yaw column are written together.  "late_handover": -1
  * (default: chosen per launch), 0, 1 = when the compute wave hands a tick's log values to the store
  * wave.  "lds_pad": extra LDS bytes per rollout workgroup (caps the workgroups a CU takes; 0).
+ * "solve_order" is NOT a tuning knob -- it selects the elimination order of the coefficient solve and with
+ * it the rounding: 1 (default) = two-ended, two lanes per mission that meet at the middle knot
+ * (csrc/minsnap_solve_tw.hip); 0 = one-ended (csrc/minsnap_solve_bt.hip, rounds 1-4), kept as the
+ * cross-check; the two agree to ~5e-14 relative on the coefficients.
  * "idle_waves": -1 (default: chosen per launch), 0, 1 = a placeholder wave between the compute and the
  * store wave of every rollout workgroup, which lets two workgroups on a CU occupy all four SIMDs
  * (16 385 .. 32 768 UAVs).  "coeff_dma": -1 (default: chosen per launch), 0, 1, 2 = the plan-fed rollout's mode: 0 the compute

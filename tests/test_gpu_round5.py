@@ -72,3 +72,49 @@ def test_clock_probe_reads_a_plausible_shader_clock(eng):
     assert 1.0 < eng.clock_probe_ghz(probe) < 2.6
     with pytest.raises(Exception):
         eng.clock_probe_begin(0)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 7, 8, 9, 12, 20, 33])
+def test_two_ended_solve_agrees_with_the_one_ended_solve_and_with_itself(eng, m):
+    """The coefficient solve eliminates a mission's knots from BOTH ends with two lanes that meet at the middle knot (round 5,
+    csrc/minsnap_solve_tw.hip; the tail lane runs the head's code on the time-reversed mission, J = diag(-1, 1, -1, -1) maps the knot
+    unknowns back).  Another rounding than the one-ended kernel of rounds 1-4 (`solve_order` 0): the coefficients agree to 1e-12
+    relative, both sit equally close to the reference formulation's dense pivoted solve, and every launch shape of the two-ended
+    kernel gives the same bits -- missions per wave, blocks parked in HBM / LDS / registers -- for uniform and ragged batches
+    (knot counts even and odd, m = 1 without any unknown, m = 2 with the junction alone); a ragged mission equals the mission alone."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    wps = mo.synthetic_missions(333, m)
+    ragged = [w[: 2 + (i % m)] for i, w in enumerate(wps)]
+    try:
+        eng.ctx.set_option("solve_order", 0)
+        p0 = eng.plan(wps, 3.0, 0.01)
+        r0 = eng.plan_ragged(ragged, 3.0, 0.01)
+        eng.ctx.set_option("solve_order", 1)
+        got = {}
+        for lanes, keep, park in ((64, 0, 0), (32, 0, 0), (16, 0, 0), (64, 1, 0), (-1, -1, -1), (64, 0, 1), (32, 0, 1)):
+            eng.ctx.set_option("solve_lanes", lanes)
+            eng.ctx.set_option("solve_keep", keep)
+            eng.ctx.set_option("solve_park", park)
+            p1 = eng.plan(wps, 3.0, 0.01)
+            r1 = eng.plan_ragged(ragged, 3.0, 0.01)
+            got[(lanes, keep, park)] = (p1.coeffs.clone(), r1.coeffs.clone(), p1.traj.clone(), r1.traj.clone())
+    finally:
+        for k, v in (("solve_order", 1), ("solve_lanes", -1), ("solve_keep", -1), ("solve_park", -1)):
+            eng.ctx.set_option(k, v)
+    base = got[(64, 0, 0)]
+    for k, v in got.items():
+        for x, y in zip(base, v):
+            assert torch.equal(x, y), k
+    scale = p0.coeffs.abs().max().clamp(min=1.0)
+    assert float((base[0] - p0.coeffs).abs().max() / scale) < 1e-12 and float((base[1] - r0.coeffs).abs().max() / scale) < 1e-12
+    so = r1.seg_offsets.cpu().numpy()
+    for i in (0, 1, m - 1, 100, 332):                       # a ragged mission == the same waypoints planned alone
+        k = len(ragged[i]) - 1
+        alone = eng.plan(np.stack([ragged[i]] * 3), 3.0, 0.01)
+        assert torch.equal(alone.coeffs[0], r1.coeffs[so[i]:so[i] + k].reshape(8 * k, 3)), i
+    for b in (7, 200):                                      # SURVEY 8(c) metric against the reference formulation (NumPy oracle, dense solve)
+        ref = mo.plan(wps[b], 3.0, 0.01, method="solve")
+        for plan in (p0, p1):
+            err = float(np.max(np.max(np.abs(plan.mission(b) - ref), axis=0) / np.maximum(1.0, np.max(np.abs(ref), axis=0))))
+            assert err < 1e-8, (b, err)

@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                           int32_t *status, const int64_t *seg_offsets, const int64_t *guard_rows, int64_t guard_capacity,
                           const int32_t *active) {
+    if (ctx->solve_order == 1) return uavac_launch_solve_tw(ctx, wp, times, B, m, coeffs, status, seg_offsets, guard_rows, guard_capacity, active);
     const size_t need = (size_t)(m > 1 ? m - 1 : 1) * 28 * (size_t)B;
     if (need > ctx->ws_cap) {
         if (ctx->d_ws) UAVAC_HIP(ctx, hipFree(ctx->d_ws));

@@ -324,6 +324,9 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
         ctx->log_pitch = value;
     } else if (n == "late_handover") {
         ctx->late_handover = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "solve_order") {
+        if (value != 0 && value != 1) return uavac_fail(ctx, UAVAC_EINVAL, "solve_order is 0 (one-ended) or 1 (two-ended)");
+        ctx->solve_order = value;
     } else if (n == "solve_park") {
         ctx->solve_park = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "solve_keep") {

@@ -36,6 +36,7 @@ struct uavac_ctx {
     int rollout_align = 1;           // tuning: launch the 2-wave aligner kernel before a logged launch of shape 1
     int late_handover = -1;          // tuning: -1 = the launcher picks per launch; 0 / 1 = slab handed over at the end of the tick / a third of a tick later
     int coeff_dma = -1;              // tuning: -1 = the launcher picks per launch; 0 / 1 / 2 = the plan-fed rollout's PMODE (control_rollout.hip)
+    int solve_order = 1;             // which elimination order solves: 1 = two-ended, two lanes per mission (minsnap_solve_tw.hip; the default), 0 = one-ended (minsnap_solve_bt.hip: other rounding, kept as the cross-check)
     int solve_park = -1;             // tuning: where the block-Thomas solve parks its forward sweep: -1 = the launcher picks, 0 = HBM workspace, 1 = LDS (when it fits)
     int solve_lanes = -1;            // tuning: lanes per wave of the block-Thomas solve that carry a mission (64 / 32 / 16; -1 = the launcher picks)
     int solve_keep = -1;             // tuning: the solve of a uniform batch keeps its first five knots' parked blocks in registers: -1 = the launcher picks, 0 / 1
@@ -155,6 +156,10 @@ int uavac_launch_row_counts(uavac_ctx *ctx, const double *wp, int B, int m, doub
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                           int32_t *status, const int64_t *seg_offsets = nullptr, const int64_t *guard_rows = nullptr,
                           int64_t guard_capacity = 0, const int32_t *active = nullptr);
+// the two-ended form (minsnap_solve_tw.hip): two lanes per mission; uavac_launch_solve_bt hands over to it unless ctx->solve_order == 0
+int uavac_launch_solve_tw(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
+                          int32_t *status, const int64_t *seg_offsets, const int64_t *guard_rows, int64_t guard_capacity,
+                          const int32_t *active);
 // One round of the obstacle loop on the device (minsnap_obstacles.hip): collision scan of the active missions' splines
 // (no rows stored) + midpoint insertion into the next waypoint arrays
 int uavac_launch_obstacle_scan_and_insert(uavac_ctx *ctx, const double *wp, const int64_t *seg_offsets, const double *coeffs,
