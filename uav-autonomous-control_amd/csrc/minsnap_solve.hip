@@ -103,7 +103,11 @@ __global__ void __launch_bounds__(256) row_counts_kernel(const double *__restric
         seg_rows += seg0;
         double x0 = w[0], y0 = w[1], z0 = w[2];
         bad = bad || !(isfinite(x0) && isfinite(y0) && isfinite(z0));
-        auto segment = [&](int s, double x1, double y1, double z1) {
+        // (one wave per SIMD at B = 65 536 and a square root and two divisions per segment, each a chain of dependent Newton
+        // steps: four segments side by side fill the gaps)
+#pragma unroll 4
+        for (int s = 0; s < m; ++s) {
+            double x1 = w[3 * s + 3], y1 = w[3 * s + 4], z1 = w[3 * s + 5];
             double dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
             double T = sqrt(fma(dz, dz, fma(dy, dy, dx * dx))) / velocity;
             if (s == 0 || s == m - 1) T = T * 1.5;      // START_END_TIME_FACTOR, minimum_snap.py:10,318-320
@@ -114,23 +118,6 @@ __global__ void __launch_bounds__(256) row_counts_kernel(const double *__restric
             seg_rows[s] = rows;
             total += rows;
             x0 = x1; y0 = y1; z0 = z1;
-        };
-        constexpr int kPreload = 20;                    // segments whose end points are all requested before the first is used
-        if (m <= kPreload) {
-            // A lane's waypoints lie (m + 1) x 24 bytes from its neighbour's: every load is 64 lines, and with the loads in the loop
-            // the kernel waited out one memory round trip per unrolled group -- 25 us at B = 65 536, m = 12 for 2 us of arithmetic.
-            // All of a mission's waypoints are asked for at once (up to 60 doubles in flight per lane), then the segments follow.
-            double W[3 * kPreload];
-#pragma unroll
-            for (int i = 0; i < 3 * kPreload; ++i) W[i] = (i < 3 * m) ? w[3 + i] : 0.0;
-#pragma unroll
-            for (int s = 0; s < kPreload; ++s)
-                if (s < m) segment(s, W[3 * s], W[3 * s + 1], W[3 * s + 2]);
-        } else {
-            // (one wave per SIMD at B = 65 536 and a square root and two divisions per segment, each a chain of dependent Newton
-            // steps: four segments side by side fill the gaps)
-#pragma unroll 4
-            for (int s = 0; s < m; ++s) segment(s, w[3 * s + 3], w[3 * s + 4], w[3 * s + 5]);
         }
         if (total > 2147483647LL) { atomicOr(&flags[3], 1); total = 0; }     // a mission's rows are indexed with int
         totals[b] = (int32_t)total;
