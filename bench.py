@@ -105,7 +105,7 @@ def kept_measurement(name, key, kernel=None):
     return rec.get(key)
 
 
-PLANNING_SOURCES = ("csrc/minsnap_sample_stream.hip", "csrc/minsnap_solve_bt.hip", "csrc/minsnap_solve.hip", "csrc/minsnap_eval.h",
+PLANNING_SOURCES = ("csrc/minsnap_sample_stream.hip", "csrc/minsnap_solve_tw.hip", "csrc/minsnap_solve_bt.hip", "csrc/minsnap_solve.hip", "csrc/minsnap_eval.h",
                     "csrc/minsnap_yaw.h")
 
 

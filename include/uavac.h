@@ -139,7 +139,8 @@ int uavac_clock_probe_dev(uavac_ctx *ctx, int window_us, int64_t *stamps);
  * coefficients arriving by LDS-DMA an outer tick ahead; 2 the second (store) wave owns the cursor and evaluates the rows in
  * its idle time (kernels that have one; inner_per_outer >= 7).  Same bits in every mode.  "solve_park": -1 (default: chosen per launch), 0, 1 = the coefficient solve parks its forward sweep in the HBM
  * workspace / in LDS (when (m - 1) x 14 KB fit; same bits); "solve_lanes": -1 (default: chosen per launch), 64, 32, 16 = lanes
- * of a wavefront of the solve that carry a mission (fewer = more wavefronts for the same batch; same bits); "solve_keep": -1
+ * of a wavefront of the solve that carry (half of) a mission -- the two-ended solve gives a mission two lanes: 32, 16, 8 missions
+ * per wavefront -- (fewer = more wavefronts for the same batch; same bits); "solve_keep": -1
  * (default: chosen per launch), 0, 1 = the solve of a uniform batch keeps the first five knots' blocks of its forward sweep in
  * registers instead of the workspace (same bits).  "sampler_waves": 4 (default), 2, 8, 16 = wavefronts per workgroup of the
  * chunk-streaming sampler, "sampler_group": 1 (default) .. 64 = consecutive missions per workgroup;

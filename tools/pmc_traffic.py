@@ -29,7 +29,7 @@ from bench import B_PER_GPU, CHUNK, F, planning_source_sha, rollout_source_sha  
 OUT = os.path.join(ROOT, "gpurun_out")
 TAG = os.environ.get("UAVAC_PROFILE_TAG", "r05")          # round tag of the files written
 KERNELS = {"control_rollout": "control_rollout_kernel", "minsnap_sample": "minsnap_sample_stream_kernel",
-           "minsnap_solve": "minsnap_solve_bt_kernel"}
+           "minsnap_solve": "minsnap_solve_tw_kernel"}      # (the two-ended solve is the default since round 5)
 
 
 def collect(counter):

@@ -1,4 +1,6 @@
-// Minimum-snap coefficient solve, thread-per-mission block-Thomas form (gfx950).
+// Minimum-snap coefficient solve, thread-per-mission block-Thomas form (gfx950) -- ONE-ENDED: the solver of rounds 1-4, since round 5
+// the cross-check of the two-ended form in minsnap_solve_tw.hip (ctx option "solve_order" = 0 selects this file; same system, other
+// elimination order, other rounding).
 //
 // Same QP and same knot-derivative coordinates as minsnap_solve.hip (see its header for the derivation
 // and for the reference lines it replaces: uav_ac/planning/minimum_snap.py:138-255).  Ordered by knot,
