@@ -32,7 +32,7 @@ for B, m in ((65536, 12), (65536, 20), (65536, 8)):
                 if r["Counter_Name"] == counter and "minsnap_solve_" in r["Kernel_Name"] and "_kernel" in r["Kernel_Name"] and "row_counts" not in r["Kernel_Name"]:
                     vals.append(float(r["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0))
                     durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-                    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+                    name = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0]
             vals, durs = vals[len(vals) // 2:], durs[len(durs) // 2:]
             rec["kernel"] = name
             rec["write_bytes" if counter == "WRITE_SIZE" else "fetch_bytes_x2"] = sum(vals) / len(vals)

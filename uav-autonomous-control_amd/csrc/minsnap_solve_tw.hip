@@ -217,7 +217,10 @@ __global__ void __launch_bounds__(TB) minsnap_solve_tw_kernel(const double *__re
     if (active) {                                                 // obstacle loop: a wave none of whose missions is active leaves at once
         if (!__any(live && active[b] != 0)) return;
     }
-    __shared__ double stage[TB * 25];                 // one segment's 24 coefficients per LANE (+1 pad)
+    // one segment's 24 coefficients per LANE (+1 pad) -- and, before the substitution starts, the waiting place of ONE more block per
+    // lane ([28][64]): the block of view knot nel - 2 is the first one the substitution asks for (in its step 0, before that step
+    // writes the stage), so it spends the end of the elimination here instead of in HBM
+    __shared__ double stage[TB * 28];
     extern __shared__ double park_lds[];              // PARK_LDS: [knots of a lane][28][2 NM]; NREG > 0: [28][64]
     __shared__ int64_t seg0_of[RAGGED ? 32 : 1];      // ragged: first segment and segment count of every mission slot
     __shared__ int m_of[RAGGED ? 32 : 1];
@@ -244,9 +247,13 @@ __global__ void __launch_bounds__(TB) minsnap_solve_tw_kernel(const double *__re
     auto tv = [&](int s) -> double { return tm[tail ? m - 1 - s : s]; };                 // duration of view segment s
     // where view knot kk's block waits, and how far apart its 28 values are
     const int slot = (tail ? NM : 0) + (q < NM ? q : 0);
-    auto park_stride = [&](int kk) -> size_t { return (NREG > 0 && kk == NREG) ? (size_t)TB : (PARK_LDS ? (size_t)(2 * NM) : sB); };
+    auto in_stage = [&](int kk) -> bool { return !PARK_LDS && kk == nel - 2 && !(NREG > 0 && kk <= NREG); };
+    auto park_stride = [&](int kk) -> size_t {
+        return ((NREG > 0 && kk == NREG) || in_stage(kk)) ? (size_t)TB : (PARK_LDS ? (size_t)(2 * NM) : sB);
+    };
     auto park_at = [&](int kk) -> double * {
         if (NREG > 0 && kk == NREG) return park_lds + lane;
+        if (in_stage(kk)) return stage + lane;
         if (PARK_LDS) return park_lds + (size_t)kk * 28 * (2 * NM) + slot;
         return ws + ((size_t)(tail ? nk - 1 - kk : kk) * 28) * sB + bb;       // (row = the knot's index in the mission)
     };
@@ -309,12 +316,13 @@ __global__ void __launch_bounds__(TB) minsnap_solve_tw_kernel(const double *__re
             double *o = park_at(kk);
             const size_t ost = park_stride(kk);
             const bool in_regs = (NREG > 0 && kk < NREG) || kk == nel - 1;      // (this lane's last block is what its substitution starts from)
+            const bool to_stage = in_stage(kk);                                 // (a lane's own column of the stage: any lane may use it)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (!in_regs && parks) o[(size_t)(i * 4 + j) * ost] = R[i][j]; }
+                for (int j = 0; j < 4; ++j) { Ut[i][j] = R[i][j]; if (!in_regs && (parks || to_stage)) o[(size_t)(i * 4 + j) * ost] = R[i][j]; }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (!in_regs && parks) o[(size_t)(16 + i * 3 + a) * ost] = R[i][4 + a]; }
+                for (int a = 0; a < 3; ++a) { rt[i][a] = R[i][4 + a]; if (!in_regs && (parks || to_stage)) o[(size_t)(16 + i * 3 + a) * ost] = R[i][4 + a]; }
             }
             if (NREG > 0 && kk < NREG) {
 #pragma unroll
@@ -517,13 +525,15 @@ int uavac_launch_solve_tw(uavac_ctx *ctx, const double *wp, const double *times,
     const int waves = (B + nm - 1) / nm;
     const int lane_knots = m > 1 ? (m - 1) / 2 : 0;                       // most blocks one lane parks
     const size_t park = (size_t)lane_knots * 28 * (2 * nm) * sizeof(double);
-    const size_t static_lds = sizeof(double) * TB * 25 + (seg_offsets ? 32 * 12 : 12);
+    const size_t static_lds = sizeof(double) * TB * 28 + (seg_offsets ? 32 * 12 : 12);
     const bool fits = lane_knots > 0 && park + static_lds <= (size_t)150 * 1024;
     const int per_cu = fits ? (int)(((size_t)156 * 1024) / (park + static_lds)) : 0;
     const bool lds_park = fits && (ctx->solve_park >= 0 ? ctx->solve_park != 0 : waves <= cus * (per_cu < 8 ? per_cu : 8));
-    // (a lane with a single block to hold has nothing to keep: m <= 4 runs 28 against 34 us at B = 65 536 without the 484-register form)
+    // (a lane with up to three blocks has little to keep -- one waits in the stage, one where it was computed: at m = 8 the 196-register
+    // form at two waves per SIMD runs 55.5 against 59.3 us at B = 65 536 and 213 against 227 at 262 144; from four blocks on -- m = 12:
+    // 85.8 against 99.2 -- the 484-register form wins)
     const bool keep = !seg_offsets && !lds_park &&
-                      (ctx->solve_keep >= 0 ? ctx->solve_keep != 0 : (ctx->solve_lanes < 0 && waves32 >= ctx->n_simds && lane_knots >= 2));
+                      (ctx->solve_keep >= 0 ? ctx->solve_keep != 0 : (ctx->solve_lanes < 0 && waves32 >= ctx->n_simds && lane_knots >= 4));
     const dim3 grid(keep ? waves32 : waves);
 #define UAVAC_SOLVE_LAUNCH(R, P, N, K)                                                                                             \
     do {                                                                                                                            \
