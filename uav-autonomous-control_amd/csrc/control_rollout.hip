@@ -813,8 +813,6 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     const int threads = NU + (LOGGING ? 64 * (1 + n_idle) : 0);
     const size_t lds = sizeof(double) * (2 * NR * NU + (POLY ? CW * poly_tile_doubles(YS) : 0) + (PMODE == 2 ? 10 * NU : 0));
     auto kern = control_rollout_kernel<CW, SW, LS, LC, AB, POLY, GR, YS, PMODE>;
-    if (lds + (size_t)ctx->lds_pad > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)ctx->lds_pad));
     // With a second wave per workgroup the launch holds at most one workgroup per SIMD; a batch with more 64-UAV tiles than
     // the chip has SIMDs is walked by those workgroups pass after pass inside ONE launch (persistent tiles, see the kernel).
     // Round 2 issued one launch per 65 536 columns instead (a single launch with two workgroups per SIMD had been measured
@@ -832,10 +830,28 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     // before the target rows left the compute wave's outer tick).  Option "late_handover" still forces either.
     const int late = ctx->late_handover >= 0 ? ctx->late_handover : 1;
     (void)cols;
+    // WORKGROUPS PER CU.  Below a full chip nothing but LDS limits how many of these workgroups a CU takes (registers allow four),
+    // and the dispatcher does not deal them evenly: at 512 workgroups on 256 CUs some CUs get three and some one, and the launch ends
+    // with its slowest CU.  The workgroup therefore asks for as much LDS as makes k + 1 of them NOT fit a CU, k = the number every CU
+    // must take (round 5, profiles/r05_cu_balance.jsonl: 32 768 UAVs 0.878 -> 0.849 and 0.869 -> 0.854 ms per 1 000 ticks on two
+    // boxes; no effect where k workgroups per CU is what happens anyway).  Option "cu_balance" = 0 switches it off; "lds_pad" > 0
+    // overrides it.  (A full chip needs nothing: four workgroups per CU is all its registers hold.)
+    size_t pad = (size_t)ctx->lds_pad;
+    if (LOGGING && pad == 0 && ctx->cu_balance != 0) {
+        const int cus = ctx->n_simds / 4;
+        const int k = (grid + cus - 1) / cus;
+        if (k >= 1 && k <= 3) {
+            const size_t lds_cu = (size_t)160 * 1024;
+            const size_t want = ((lds_cu / (size_t)(k + 1) + 1024) + 1023) & ~(size_t)1023;
+            if (want * (size_t)k <= lds_cu && want > lds) pad = want - lds;
+        }
+    }
     const size_t pitch = (LS || LC) ? (ctx->log_pitch > 0 ? (size_t)ctx->log_pitch : (size_t)B) : (size_t)B;
     if (LOGGING && ctx->rollout_align)
         hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(threads), 0, ctx->stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds + (size_t)ctx->lds_pad, ctx->stream, V, traj, row_offsets, state, istate,
+    if (lds + pad > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds + pad, ctx->stream, V, traj, row_offsets, state, istate,
                        B, K, state_log, cmd_log, aabbs, n_obs, n_tiles, pitch, P, late, n_idle);
     auto tf = [](bool v) { return v ? "true" : "false"; };
     char name[176];

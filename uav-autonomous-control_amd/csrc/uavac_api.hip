@@ -338,6 +338,8 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
         ctx->coeff_dma = value < 0 ? -1 : (value > 2 ? 2 : value);
     } else if (n == "idle_waves") {
         ctx->idle_waves = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "cu_balance") {
+        ctx->cu_balance = value ? 1 : 0;
     } else if (n == "lds_pad") {
         if (value < 0 || value > 120 * 1024) return uavac_fail(ctx, UAVAC_EINVAL, "lds_pad is 0 .. 122880 bytes");
         ctx->lds_pad = value & ~7;

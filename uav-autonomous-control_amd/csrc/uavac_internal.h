@@ -41,6 +41,7 @@ struct uavac_ctx {
     int solve_lanes = -1;            // tuning: lanes per wave of the block-Thomas solve that carry a mission (64 / 32 / 16; -1 = the launcher picks)
     int solve_keep = -1;             // tuning: the solve of a uniform batch keeps its first five knots' parked blocks in registers: -1 = the launcher picks, 0 / 1
     int idle_waves = -1;             // tuning: placeholder wave between compute and store wave (0 / 1); -1 = the launcher picks
+    int cu_balance = 1;              // tuning: a logged rollout below a full chip asks for as much LDS per workgroup as keeps a CU from taking more workgroups than its even share (0: off)
     int lds_pad = 0;                 // tuning: extra dynamic LDS per rollout workgroup (bytes): caps the workgroups a CU takes
     int64_t log_pitch = 0;           // doubles per row of the rollout's logs; 0 = B (option "log_pitch")
     int n_simds = 1024;              // SIMDs of the device (4 per CU): the logged rollout launches one workgroup per SIMD at most
