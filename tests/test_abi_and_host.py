@@ -174,6 +174,7 @@ def test_row_prefetch_lands_in_the_carried_registers_and_no_diagnostics_ship():
     if not os.path.exists(os.path.join(PKG, "build", "control_rollout.o")):
         pytest.skip("no object files here (library built elsewhere)")
     assert _buildcheck.check_row_prefetch() == 16
+    assert _buildcheck.check_heading_prefetch() >= 20          # the sampler's LDS prefetch of the heading coefficients, same rule
     assert _buildcheck.check_no_diagnostics() is True
     for name in os.listdir(os.path.join(PKG, "csrc")):
         with open(os.path.join(PKG, "csrc", name)) as f:

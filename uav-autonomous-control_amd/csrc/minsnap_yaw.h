@@ -102,6 +102,9 @@ __device__ __forceinline__ double heading(double y, double x) {
     return heading_with(y, x, lit);
 }
 
+// (The loads' operands are output-only and the compiler does not know the data to be in flight: uav_ac/_buildcheck.py
+// check_heading_prefetch() verifies in the disassembly of every sampler variant that nothing touches the destination registers
+// between the ten loads and the wait -- the rule of the rollout's row prefetch.)
 // The coefficients as ten 16-byte LDS reads into registers that live for the length of one call (lds = LDS byte address of a
 // copy of kHeadingPoly, 16-byte aligned).  The reads are issued in begin() and waited for in ready(), the division in between.
 struct HeadingFromLds {

@@ -161,6 +161,42 @@ def check_row_prefetch(obj: str = None):
     return checked
 
 
+_LDS_LOAD = re.compile(r"ds_read_b128 v\[(\d+):(\d+)\], (v\d+)(?: offset:(\d+))?$")
+
+
+def check_heading_prefetch(obj: str = None):
+    """The streaming sampler fetches the heading polynomial's twenty coefficients from LDS with ten `ds_read_b128` the compiler does not
+    know to be in flight (minsnap_yaw.h, HeadingFromLds::begin / ready) while the division runs.  Same question as for the rollout's row
+    prefetch, same answer: in every sampler variant, between each group of ten such loads and the next `s_waitcnt ... lgkmcnt(0)` no
+    instruction touches a destination register and no branch intervenes.  Raises RuntimeError otherwise; returns the number of groups
+    checked, None when the object file cannot be read."""
+    kernels = _disassemble(obj or os.path.join(PKG, "build", "minsnap_sample_stream.o"))
+    if kernels is None:
+        return None
+    groups, bad = 0, []
+    for name, ins in kernels.items():
+        if "minsnap_sample_stream_kernel" not in name:
+            continue
+        i = 0
+        while i + 9 < len(ins):
+            ms = [_LDS_LOAD.match(x) for x in ins[i:i + 10]]
+            if not (all(ms) and [int(m.group(4) or 0) for m in ms] == list(range(0, 160, 16)) and len({m.group(3) for m in ms}) == 1):
+                i += 1
+                continue
+            dest = {r for m in ms for r in range(int(m.group(1)), int(m.group(2)) + 1)}
+            groups += 1
+            j = i + 10
+            while j < len(ins) and not re.match(r"s_waitcnt .*lgkmcnt\(0\)", ins[j]):
+                if _vregs(ins[j]) & dest or ins[j].startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                    bad.append((name[:80], f"'{ins[j]}' between the coefficient loads and their wait"))
+                    break
+                j += 1
+            i += 10
+    if bad or groups < 20:
+        raise RuntimeError(f"heading prefetch of the streaming sampler: {groups} load groups checked; {bad} (compiler: {compiler_version()})")
+    return groups
+
+
 def check_no_diagnostics(lib_path: str = None):
     """The shipped library exports no diagnostic entry point (`uavac_diag_*`): those exist only in tools/diag builds."""
     lib_path = lib_path or os.path.join(PKG, "lib", "libuavac.so")
