@@ -594,12 +594,16 @@ def main():
         plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)
         fleet4 = eng.fleet(plan4)
         pitch4 = -(-B4 // 16) * 16                                                               # rows on 128-byte lines for any B4
-        log4 = torch.empty((CHUNK, 13, pitch4), dtype=torch.float64, device=dev)
+        # The 5 000 ticks in as few launches as a 40 GB log allows: ONE at 8 ranks (17-19 GB), two at 2 ranks, five on one GPU.  A
+        # launch boundary costs 50-80 us below a full chip (every workgroup waits for the slowest; prologue; aligner): 32 768 UAVs fly
+        # the 5 000 ticks in 4.19 ms as one launch against 4.48 as five (profiles/r05_config4_chunking.jsonl).
+        chunk4 = next(c for c in (5000, 2500, 1000) if c == 1000 or c * 13 * pitch4 * 8 <= 40e9)
+        log4 = torch.empty((chunk4, 13, pitch4), dtype=torch.float64, device=dev)
 
         def fly4():
             fleet4.reset()
-            for _ in range(C4_TICKS // CHUNK):
-                fleet4.rollout(CHUNK, state_log=log4, log_pitch=pitch4)
+            for _ in range(C4_TICKS // chunk4):
+                fleet4.rollout(chunk4, state_log=log4, log_pitch=pitch4)
 
         def step4():
             eng.replan(plan4)
@@ -632,11 +636,12 @@ def main():
         b.record()
         torch.cuda.synchronize()
         c4 = {"workload": "BASELINE.json configs[3]: 262144 UAVs in total (strong scaling), 8-segment missions, plan + "
-                          "5000 fused ticks (5 launches x 1000, state logged), trajectories gathered to rank 0",
+                          "5000 fused ticks (state logged every tick; as few launches as a 40 GB log per rank allows: `ticks_per_launch`), "
+                          "trajectories gathered to rank 0",
               "batch_total": C4_TOTAL, "batch_per_gpu": B4, "shard_sizes": sizes4, "root_share": root_share,
               "tick_table": ([[int(n), round(us, 4), round(pm, 5)] for n, us, pm in tick_table] if tick_table else None),
               "tick_table_columns": "missions on the GPU, us per logged tick, ms of planning per 1000 missions (max over ranks)",
-              "log_pitch": pitch4,
+              "log_pitch": pitch4, "ticks_per_launch": chunk4,
               "segments": C4_SEGMENTS, "ticks": C4_TICKS,
               "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
               "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel(),

@@ -955,15 +955,16 @@ def shard_bounds(B: int, rank: int, world: int, root_share: float = None, root: 
 # One MI355X, measured (round 4: profiles/r04_config_sweep.jsonl, tools/rollout_ab.py, m = 8 .. 12): UAVs in flight on the GPU,
 # us per logged tick, ms of the planning chain per 1 000 missions.  A FALLBACK: `measure_tick_table` measures the same three
 # columns on the GPU at hand in a few tens of milliseconds, and `bench.py --gpus N` does so before it cuts the shards.
-DEFAULT_TICK_TABLE = ((4096, 0.753, 0.028), (16384, 0.792, 0.0180), (24576, 0.86, 0.0178), (32768, 0.885, 0.0177), (49152, 1.02, 0.0176),
-                      (65536, 1.28, 0.0176))
+DEFAULT_TICK_TABLE = ((4096, 0.787, 0.027), (16384, 0.792, 0.0180), (24576, 0.843, 0.0170), (32768, 0.857, 0.0163), (35237, 0.876, 0.0163),
+                      (49152, 1.019, 0.0163), (65536, 1.262, 0.0163))
 
 
-def measure_tick_table(engine: "Engine", segments: int, sizes, velocity: float = 3.0, dt: float = 0.01, ticks: int = 500,
-                       launches: int = 3, seed: int = 7):
+def measure_tick_table(engine: "Engine", segments: int, sizes, velocity: float = 3.0, dt: float = 0.01, ticks: int = 2500,
+                       launches: int = 2, seed: int = 7):
     """What a shard of n missions costs on THIS GPU, for every n in `sizes`: [(n, us per logged tick, ms of the planning chain
     per 1 000 missions)].  Synthetic missions of the SURVEY 8(d) shape, planned once more after a warm-up, then `launches`
-    logged launches of `ticks` ticks (the first is thrown away).  A few tens of milliseconds per size."""
+    logged launches of `ticks` ticks (the first is thrown away; long launches, as the job itself flies them: a launch boundary
+    costs 50-80 us below a full chip).  A few tens of milliseconds per size."""
     torch = engine._torch
     rng = np.random.default_rng(seed)
     table = []
