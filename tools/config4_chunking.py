@@ -32,5 +32,25 @@ for chunk in (1000, 2500, 5000):
     out[f"chunk_{chunk}"] = {"ms_reset_plus_flight": round(float(np.median(times)), 4), "G_steps_per_s": round(B * K / float(np.median(times)) / 1e6, 2),
                              "ms_per_launch": [round(float(x), 4) for x in np.median(np.array(per), axis=0)]}
     del log
+# the job as a rank runs it: the planning chain in front of every flight (other kernels, other workgroup shapes: does the flight
+# behind them start from the same wave placement?) -- flight part alone, one launch
+log = torch.empty((K, 13, pitch), dtype=torch.float64, device="cuda:0")
+for align in (1, 2):
+    fl = []
+    for rep in range(6):
+        eng.replan(plan)
+        a, b = ev(), ev()
+        a.record()
+        fleet.reset()
+        if align == 2:                       # a second aligner launch in front (the library issues one itself)
+            fleet.rollout(1, state_log=log, log_pitch=pitch)
+            fleet.reset()
+        fleet.rollout(K, state_log=log, log_pitch=pitch)
+        b.record(); torch.cuda.synchronize()
+        if rep:
+            fl.append(a.elapsed_time(b))
+    out["after_replan_one_launch" + ("" if align == 1 else "_behind_a_1_tick_launch")] = {"ms_reset_plus_flight": round(float(np.median(fl)), 4),
+                                                                                       "G_steps_per_s": round(B * K / float(np.median(fl)) / 1e6, 2)}
+del log
 out["kernel"] = eng.ctx.last_rollout_kernel()
 print(json.dumps(out))
