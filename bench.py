@@ -697,10 +697,11 @@ def main():
                 # which physical GPU every rank flew on, gathered over the process group: N ranks must name N devices
                 idents = [None] * world
                 dist.all_gather_object(idents, eng.ctx.device_identity())
+                # (distinct by uuid AND PCI address: a runtime that reports no uuid still tells its devices apart by bus id)
                 if rank == 0:
                     c4["devices"] = idents
-                    c4["distinct_devices"] = len({i.split(";")[0] for i in idents})
-                if len({i.split(";")[0] for i in idents}) != world and not rehearsal:
+                    c4["distinct_devices"] = len(set(idents))
+                if len(set(idents)) != world and not rehearsal:
                     raise RuntimeError(f"{world} ranks on {len(set(idents))} distinct GPUs: {idents}")
 
                 # ---- the gather of the ROWS: once untimed (allocation, verification), then timed
