@@ -451,6 +451,7 @@ def main():
                         "ms_median": float(np.median(plan_ms)), "ms_min": float(np.min(plan_ms)), "ms_max": float(np.max(plan_ms)),
                         "frac_median": plan.algorithmic_bytes / (float(np.median(plan_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "row_buffer": "first allocation (Engine.plan's default: no placement search)",
+                        "solve": "two-ended block-Thomas, two lanes per mission (csrc/minsnap_solve_tw.hip; option solve_order = 1, the default)",
                         "frac_first_allocation": plan.algorithmic_bytes / plan_med_s / 1e9 / HBM_PEAK_GBS,
                         "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_med_s / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
