@@ -118,3 +118,35 @@ def test_two_ended_solve_agrees_with_the_one_ended_solve_and_with_itself(eng, m)
         for plan in (p0, p1):
             err = float(np.max(np.max(np.abs(plan.mission(b) - ref), axis=0) / np.maximum(1.0, np.max(np.abs(ref), axis=0))))
             assert err < 1e-8, (b, err)
+
+
+@pytest.mark.parametrize("B", [1000, 20480, 35000])
+def test_workgroups_per_cu_cap_changes_no_result(eng, B):
+    """Below a full chip the launcher sizes a logged rollout's LDS so that no CU takes more workgroups than its even share (option
+    "cu_balance", 81 / 55 / 41 KB of dynamic LDS for one / two / three workgroups per CU): a matter of where workgroups run, never
+    of what they compute -- state log, command log, final state and flags are the same bit for bit with the cap on and off,
+    plan-fed and row-fed."""
+    import torch
+    plan = eng.plan(_missions(B, 4), 3.0, 0.01)
+    K = 130
+    out = {}
+    try:
+        for cap in (0, 1):
+            eng.ctx.set_option("cu_balance", cap)
+            for feed in (True, False):
+                f = eng.fleet(plan, from_plan=feed)
+                s, c = f.rollout(K, state_log=True, cmd_log=True, aabbs=LAB_AABBS)
+                out[(cap, feed)] = (s.clone(), c.clone(), f.state[:26].clone(), f.istate.clone())
+    finally:
+        eng.ctx.set_option("cu_balance", 1)
+    for feed in (True, False):
+        for x, y in zip(out[(0, feed)], out[(1, feed)]):
+            assert torch.equal(x, y), feed
+    for x, y in zip(out[(1, True)][:2], out[(1, False)][:2]):
+        assert torch.equal(x, y)
+
+
+def test_solve_order_is_zero_or_one(eng, nat):
+    with pytest.raises(nat.UavacError):
+        eng.ctx.set_option("solve_order", 2)
+    eng.ctx.set_option("solve_order", 1)
