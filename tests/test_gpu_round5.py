@@ -123,7 +123,7 @@ def test_two_ended_solve_agrees_with_the_one_ended_solve_and_with_itself(eng, m)
 @pytest.mark.parametrize("B", [1000, 20480, 35000])
 def test_workgroups_per_cu_cap_changes_no_result(eng, B):
     """Below a full chip the launcher sizes a logged rollout's LDS so that no CU takes more workgroups than its even share (option
-    "cu_balance", 81 / 55 / 41 KB of dynamic LDS for one / two / three workgroups per CU): a matter of where workgroups run, never
+    "cu_balance", 55 / 41 KB of dynamic LDS for two / three workgroups per CU): a matter of where workgroups run, never
     of what they compute -- state log, command log, final state and flags are the same bit for bit with the cap on and off,
     plan-fed and row-fed."""
     import torch

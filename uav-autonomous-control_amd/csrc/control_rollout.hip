@@ -833,14 +833,16 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     // WORKGROUPS PER CU.  Below a full chip nothing but LDS limits how many of these workgroups a CU takes (registers allow four),
     // and the dispatcher does not deal them evenly: at 512 workgroups on 256 CUs some CUs get three and some one, and the launch ends
     // with its slowest CU.  The workgroup therefore asks for as much LDS as makes k + 1 of them NOT fit a CU, k = the number every CU
-    // must take (round 5, profiles/r05_cu_balance.jsonl: 32 768 UAVs 0.878 -> 0.849 and 0.869 -> 0.854 ms per 1 000 ticks on two
+    // must take, for k = 2 and 3 (round 5, profiles/r05_cu_balance.jsonl: 32 768 UAVs 0.878 -> 0.849 and 0.869 -> 0.854 ms per 1 000 ticks on two
     // boxes; no effect where k workgroups per CU is what happens anyway).  Option "cu_balance" = 0 switches it off; "lds_pad" > 0
     // overrides it.  (A full chip needs nothing: four workgroups per CU is all its registers hold.)
     size_t pad = (size_t)ctx->lds_pad;
     if (LOGGING && pad == 0 && ctx->cu_balance != 0) {
         const int cus = ctx->n_simds / 4;
         const int k = (grid + cus - 1) / cus;
-        if (k >= 1 && k <= 3) {
+        // (k = 1 is left alone: measured no gain there, and a workgroup that claims half a CU's LDS could starve beside another
+        // kernel on a second stream -- the root of config 4 re-samples its peers' rows while it flies)
+        if (k >= 2 && k <= 3) {
             const size_t lds_cu = (size_t)160 * 1024;
             const size_t want = ((lds_cu / (size_t)(k + 1) + 1024) + 1023) & ~(size_t)1023;
             if (want * (size_t)k <= lds_cu && want > lds) pad = want - lds;
