@@ -671,7 +671,7 @@ def main():
                 return int(t.item()) == 0
 
             try:
-                from uav_ac.fleet import gather_plan, gather_rows
+                from uav_ac.comm_host import gather_plan, gather_rows      # (host tensors over gloo: the rehearsal transport)
                 SLICE = 200000                             # rehearsal: rows per rank that cross gloo (control flow only)
                 if rehearsal:
                     def rows_gather():

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define UAVAC_VERSION 300 /* 0.3.0: plan gather, log pitch, row offsets from row counts; 0.2.0: ground-plane fields, istate has 4 rows */
+#define UAVAC_VERSION 310 /* 0.3.1: rows-free planning chain (uavac_minsnap_plan_dev with traj = NULL), uavac_minsnap_first_yaw_dev;
+                             0.3.0: plan gather, log pitch, row offsets from row counts; 0.2.0: ground-plane fields, istate has 4 rows */
 
 #define UAVAC_OK 0
 #define UAVAC_EINVAL (-1)    /* bad shape / size / null pointer                    */
@@ -221,11 +222,26 @@ int uavac_minsnap_sample_derivs_dev(uavac_ctx *ctx, const double *coeffs, const 
  * times, seg_rows, row_offsets, coeffs, status, traj, yaw and first_yaw all keep what they held, so the
  * previous plan stays consistent and flyable (times / row counts / offsets are computed into ctx scratch
  * and copied into the caller's arrays by a device-side commit only when the rows fit).
- * Typical use: size the buffers once with uavac_minsnap_row_counts_dev, then re-plan in place. */
+ * Typical use: size the buffers once with uavac_minsnap_row_counts_dev, then re-plan in place.
+ *
+ * ROWS-FREE form: traj == NULL (then yaw must be NULL and traj_capacity_rows is ignored).  The chain is times + row counts,
+ * row offsets, coefficient solve and -- when first_yaw != NULL -- uavac_minsnap_first_yaw_dev: everything a plan-fed rollout
+ * (uavac_control_rollout_plan_dev with yaw == NULL) and uavac_gather_plan_dev need, and not one of the 88-byte rows.  For ranks
+ * of a multi-GPU job whose trajectories are sampled where they are wanted (the root of the final gather re-samples them from
+ * the gathered plan, bit-identical): sampling them on the peer as well was the same work done twice.  Nothing can be refused,
+ * so times / seg_rows / row_offsets are written in place. */
 int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, double velocity, double dt,
                            double *times, int32_t *seg_rows, int64_t *row_offsets, double *coeffs,
                            int32_t *status, double *traj, int64_t traj_capacity_rows, double *yaw,
                            double *first_yaw);
+
+/* first_yaw [B] of a solved plan WITHOUT sampling its rows: the heading of each mission's first sample with |v_xy| >= 1e-3
+ * (MinimumSnap._calculate_yaws, minimum_snap.py:126-136: the rows before it take that heading; 0 when no sample has one) --
+ * bit for bit what the sampler writes into first_yaw, from coeffs [B][8m][3] and seg_rows [B][m] alone.  One wavefront per
+ * mission walks the rows 64 at a time from row 0 and stops at the first valid one.  seg_offsets [B+1] (device) != NULL: a
+ * ragged batch (coeffs [S][8][3], seg_rows [S] back to back, m = the largest segment count); NULL: uniform. */
+int uavac_minsnap_first_yaw_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *seg_offsets,
+                                int B, int m, double dt, double *first_yaw);
 
 /* row_offsets [B+1] from per-segment row counts that exist already -- the second half of
  * uavac_minsnap_row_counts_dev on its own, for a plan whose seg_rows [B][m] came from elsewhere (the

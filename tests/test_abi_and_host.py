@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uavac.h but not exported"
     assert sorted(nat.exported_symbols()) == declared       # the ctypes table covers the header exactly
-    assert lib.uavac_version() == nat.VERSION == 300
+    assert lib.uavac_version() == nat.VERSION == 310
 
 
 def test_vehicle_struct_layout_and_defaults():
@@ -183,21 +183,100 @@ def test_row_prefetch_lands_in_the_carried_registers_and_no_diagnostics_ship():
         assert "-Werror=inline-asm" in f.read()
 
 
-def test_row_prefetch_check_catches_a_copy_made_too_early(tmp_path):
-    """The disassembly check fails when an instruction reads a row register between the loads and their wait."""
+def _row_fed_kernel():
     from uav_ac import _buildcheck
-    kernels = _buildcheck._disassemble(os.path.join(PKG, "build", "control_rollout.o"))
+    kernels = _buildcheck._disassemble_cfg(os.path.join(PKG, "build", "control_rollout.o"))
     if kernels is None:
         pytest.skip("no object file / LLVM tools here")
     name, ins = next((n, i) for n, i in kernels.items() if "control_rollout_kernel" in n and "ELb0ELb0ELb0ELi0E" in n)
     at = max(j for j, x in enumerate(ins) if _buildcheck._ROW_LOAD.match(x) and "offset:64" in x)
-    reg = _buildcheck._ROW_LOAD.match(ins[at]).group(1)
-    tampered = dict(kernels)
-    tampered[name] = ins[:at + 1] + [f"v_mov_b32_e32 v255, v{reg}"] + ins[at + 1:]
-    real = _buildcheck._disassemble
-    _buildcheck._disassemble = lambda obj: tampered
+    return kernels, name, ins, at, _buildcheck._ROW_LOAD.match(ins[at]).group(1)
+
+
+def _check_with(kernels):
+    from uav_ac import _buildcheck
+    real = _buildcheck._disassemble_cfg
+    _buildcheck._disassemble_cfg = lambda obj: kernels
     try:
-        with pytest.raises(RuntimeError, match="touches a row register"):
-            _buildcheck.check_row_prefetch()
+        return _buildcheck.check_row_prefetch()
     finally:
-        _buildcheck._disassemble = real
+        _buildcheck._disassemble_cfg = real
+
+
+def test_row_prefetch_check_catches_a_copy_made_too_early():
+    """The disassembly check fails when an instruction reads a row register between the loads and their wait."""
+    from uav_ac._buildcheck import Ins
+    kernels, name, ins, at, reg = _row_fed_kernel()
+    assert _check_with(kernels) == 16                           # the build as it is passes
+    tampered = dict(kernels)
+    tampered[name] = ins[:at + 1] + [Ins(f"v_mov_b32_e32 v255, v{reg}")] + ins[at + 1:]
+    with pytest.raises(RuntimeError, match="touches a row register"):
+        _check_with(tampered)
+
+
+def test_row_prefetch_check_follows_branches_round_a_wait():
+    """Round-5 advice: a `s_waitcnt vmcnt(0)` that the executed path BRANCHES OVER proves nothing.  Behind the in-loop row loads:
+    a conditional branch over a wait, then an instruction that touches a row register.  In linear layout a wait precedes the
+    instruction (the round-5 check accepted that); on the control-flow graph the loads reach it without one."""
+    from uav_ac._buildcheck import Ins
+    kernels, name, ins, at, reg = _row_fed_kernel()
+    landing = 0x7fff0000                                        # an address no real instruction has
+    tampered = dict(kernels)
+    tampered[name] = (ins[:at + 1] + [Ins("s_cbranch_scc1 1", None, landing), Ins("s_waitcnt vmcnt(0)"),
+                                     Ins(f"v_mov_b32_e32 v255, v{reg}", landing)] + ins[at + 1:])
+    with pytest.raises(RuntimeError, match="touches a row register"):
+        _check_with(tampered)
+    # the same instruction behind a wait that every path crosses is fine
+    tampered[name] = ins[:at + 1] + [Ins("s_waitcnt vmcnt(0)"), Ins(f"v_mov_b32_e32 v255, v{reg}")] + ins[at + 1:]
+    assert _check_with(tampered) == 16
+    # ... and control flow the check cannot follow is refused, not waved through
+    tampered[name] = ins[:at + 1] + [Ins("s_setpc_b64 s[0:1]")] + ins[at + 1:]
+    with pytest.raises(RuntimeError, match="indirect control flow"):
+        _check_with(tampered)
+
+
+def test_a_build_check_that_cannot_run_fails_the_build(monkeypatch):
+    """`run_all` -- what __graft_entry__.build() and the autobuild of uav_ac._native.lib() call -- treats a check that cannot run
+    (no LLVM tools, no object files) as a failure, and leaves a stamp naming library and compiler when everything passed."""
+    from uav_ac import _buildcheck
+    from uav_ac import _native as nat
+    nat.lib()
+    if not os.path.exists(os.path.join(PKG, "build", "control_rollout.o")):
+        pytest.skip("no object files here (library built elsewhere)")
+    stamp = _buildcheck.run_all()
+    assert stamp == _buildcheck.read_stamp()
+    assert stamp["library_sha256"] == _buildcheck.library_sha256() and stamp["build_info"] == nat.lib().uavac_build_info().decode()
+    assert stamp["checks"]["row_prefetch"] == 16 and "clang" in stamp["checked_with"].lower()
+    monkeypatch.setattr(_buildcheck, "LLVM_BIN", "/nonexistent")
+    with pytest.raises(RuntimeError, match="could not run"):
+        _buildcheck.run_all(write_stamp=False)
+
+
+def test_autobuild_runs_the_build_checks_and_sets_a_failing_library_aside(tmp_path, monkeypatch):
+    """uav_ac._native.lib() with UAVAC_AUTOBUILD=1 and no library: `make`, then the SAME checks as __graft_entry__.build(); a
+    build that fails them is not loaded and not left in place for the next process."""
+    import shutil
+    from uav_ac import _buildcheck
+    from uav_ac import _native as nat
+    real_lib = nat.lib()
+    pkg = tmp_path / "pkg"
+    (pkg / "lib").mkdir(parents=True)
+    (pkg / "Makefile").write_text(f"all:\n\tcp {nat.LIB_PATH} {pkg}/lib/libuavac.so\n")
+    target = str(pkg / "lib" / "libuavac.so")
+    monkeypatch.setattr(nat, "LIB_PATH", target)
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setenv("UAVAC_AUTOBUILD", "1")
+    calls = []
+
+    def failing(*a, **k):
+        calls.append(1)
+        raise RuntimeError("'v_mov_b32_e32 v255, v2' touches a row register while the row loads may be in flight")
+    monkeypatch.setattr(_buildcheck, "run_all", failing)
+    with pytest.raises(nat.UavacError, match="FAILED its build checks"):
+        nat.lib()
+    assert calls and not os.path.exists(target) and os.path.exists(target + ".failed-buildcheck")
+    # with passing checks the freshly built library is loaded
+    monkeypatch.setattr(_buildcheck, "run_all", lambda *a, **k: calls.append(2) or {})
+    assert nat.lib() is not None and calls[-1] == 2 and os.path.exists(target)
+    monkeypatch.setattr(nat, "_lib", real_lib)
+    shutil.rmtree(pkg)

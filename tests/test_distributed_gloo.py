@@ -20,7 +20,8 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from uav_ac.fleet import gather_rows, shard_bounds
+    from uav_ac.comm_host import gather_rows
+    from uav_ac.sharding import shard_bounds
     from oracle.minsnap_oracle import plan, synthetic_missions
     B = 5
     lo, hi = shard_bounds(B, rank, world)
@@ -78,7 +79,8 @@ def _plan_worker(rank, world, port, out_dir, root_share=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from uav_ac.fleet import gather_plan, gather_rows, shard_bounds
+    from uav_ac.comm_host import gather_plan, gather_rows
+    from uav_ac.sharding import shard_bounds
     from oracle import minsnap_oracle as mo
     B, m, v, dt = 7, 3, 3.0, 0.01
     lo, hi = shard_bounds(B, rank, world, root_share, 0)            # uneven blocks: a small one for the gather's root

@@ -98,7 +98,7 @@ def test_rccl_world1_gather_and_loopback(eng, nat):
 
 def test_gather_rows_refuses_gpu_rows_without_a_communicator(eng):
     import torch
-    from uav_ac.fleet import gather_rows
+    from uav_ac.comm_host import gather_rows
     with pytest.raises(ValueError):
         gather_rows(torch.zeros((4, 11), dtype=torch.float64, device=eng.device))
 

@@ -1,0 +1,134 @@
+"""BASELINE configs[3] with the rows sampled ONCE (round 6): what one GPU can measure of the 8-rank job in which every rank plans
+rows-free (times, row counts, solve, first headings: Engine.plan(rows=False)), flies plan-fed and ships its plan, and rank 0
+samples all 262 144 missions' rows from the gathered plan beside its own flight.
+
+  peer:  a rank's chain at n UAVs (m = 8, 5 000 ticks in one launch) -- planning chain with rows / rows-free, then the flight
+  root:  the re-sampling of all 262 144 missions (20.9 GB of rows) on a side stream BESIDE a flight of n_root UAVs, and each alone
+
+    python3 tools/config4_rows_free.py            -> JSON lines (profiles/r06_config4_rows_free.jsonl)
+"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-autonomous-control_amd")]
+import numpy as np
+import torch
+from bench import missions, C4_TOTAL, C4_SEGMENTS, C4_TICKS, VELOCITY, DT
+from uav_ac.fleet import Engine
+
+eng = Engine("cuda:0")
+dev = eng.device
+ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+m, K = C4_SEGMENTS, C4_TICKS
+
+
+def med(xs):
+    return round(float(np.median(xs)), 4)
+
+
+def peer(n, reps=7):
+    wps = missions(C4_TOTAL, m, 0, n)
+    pitch = -(-n // 16) * 16
+    log = torch.empty((K, 13, pitch), dtype=torch.float64, device=dev)
+    out = {"leg": "peer", "uavs": n, "ticks": K}
+    for label, rows in (("with_rows", True), ("rows_free", False)):
+        plan = eng.plan(wps, VELOCITY, DT, rows=rows)
+        fleet = eng.fleet(plan, from_plan=True)
+        chain, flight, both = [], [], []
+        for rep in range(reps):
+            a, b, c = ev(), ev(), ev()
+            a.record()
+            eng.replan(plan)
+            b.record()
+            fleet.reset()
+            fleet.rollout(K, state_log=log, log_pitch=pitch)
+            c.record()
+            torch.cuda.synchronize()
+            if rep >= 2:
+                chain.append(a.elapsed_time(b)); flight.append(b.elapsed_time(c)); both.append(a.elapsed_time(c))
+        out[label] = {"plan_ms": med(chain), "flight_ms": med(flight), "plan_plus_flight_ms": med(both),
+                      "kernel": eng.ctx.last_rollout_kernel()}
+        del plan, fleet
+    out["saved_ms"] = round(out["with_rows"]["plan_plus_flight_ms"] - out["rows_free"]["plan_plus_flight_ms"], 4)
+    del log
+    torch.cuda.empty_cache()
+    return out
+
+
+def root(n_root, parts, total_rows, traj, reps=6):
+    """rank 0 of the 8-rank job on ONE GPU: its own rows-free plan + flight of n_root UAVs on the current stream, the
+    re-sampling of all 262 144 missions from the (already gathered) plan on a side stream beside it."""
+    co, tm, sr = parts
+    wps = missions(C4_TOTAL, m, 0, n_root)
+    plan = eng.plan(wps, VELOCITY, DT, rows=False)
+    fleet = eng.fleet(plan)
+    pitch = -(-n_root // 16) * 16
+    log = torch.empty((K, 13, pitch), dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    here = torch.cuda.current_stream(dev)
+    res = {"leg": "root", "uavs": n_root, "resampled_missions": C4_TOTAL, "rows": total_rows, "row_GB": round(total_rows * 88 / 1e9, 2)}
+
+    def fly():
+        eng.replan(plan)
+        fleet.reset()
+        fleet.rollout(K, state_log=log, log_pitch=pitch)
+
+    def resample(stream):
+        with torch.cuda.stream(stream):
+            eng.plan_from_parts(co, tm, sr, m, VELOCITY, DT, total_rows=total_rows, traj=traj)
+        eng._bind_stream()
+
+    # "both": which of the two is enqueued first decides everything -- the sampler's grid (262 144 workgroups, six waves of 80
+    # registers per SIMD) never leaves 256 free registers on a SIMD while it has workgroups left, so a rollout workgroup that
+    # arrives behind it waits for its LAST wave; a rollout that is resident first keeps its SIMDs and the sampler fills the rest.
+    for label in ("flight_alone", "resample_alone", "both_resample_first", "both_flight_first", "both_flight_first_hi_prio"):
+        ts = []
+        hi = torch.cuda.Stream(device=dev, priority=-1) if label.endswith("hi_prio") else None
+        for rep in range(reps):
+            torch.cuda.synchronize()
+            a, b = ev(), ev()
+            a.record()
+            if label == "both_resample_first":
+                side.wait_stream(here)
+                resample(side)
+                fly()
+                here.wait_stream(side)
+            elif label.startswith("both_flight_first"):
+                side.wait_stream(here)
+                if hi is not None:
+                    hi.wait_stream(here)
+                    with torch.cuda.stream(hi):
+                        fly()
+                    eng._bind_stream()
+                else:
+                    fly()
+                resample(side)
+                here.wait_stream(side)
+                if hi is not None:
+                    here.wait_stream(hi)
+            elif label == "flight_alone":
+                fly()
+            else:
+                resample(here)
+            b.record()
+            torch.cuda.synchronize()
+            if rep >= 2:
+                ts.append(a.elapsed_time(b))
+        res[label + "_ms"] = med(ts)
+    res["kernel"] = eng.ctx.last_rollout_kernel()
+    del plan, fleet, log
+    torch.cuda.empty_cache()
+    return res
+
+
+if __name__ == "__main__":
+    print(json.dumps({"build": __import__("bench").nat_build_info(), "gpu": eng.ctx.device_identity()}), flush=True)
+    if "--root-only" not in sys.argv:
+        for n in (32768, 35237, 36000, 36352, 36864, 37450):
+            print(json.dumps(peer(n)), flush=True)
+    # the gathered plan of the whole job (what arrives at rank 0: coefficients, durations, rows per spline)
+    allp = eng.plan(missions(C4_TOTAL, m, 0, C4_TOTAL), VELOCITY, DT, rows=False)
+    parts = (allp.coeffs.reshape(-1, 8, 3), allp.times.reshape(-1), allp.seg_rows.reshape(-1))
+    total_rows = allp.total_rows
+    traj = torch.empty((total_rows, 11), dtype=torch.float64, device=dev)
+    for n_root in (2048, 4096, 8192, 10240, 12288, 16384):
+        print(json.dumps(root(n_root, parts, total_rows, traj)), flush=True)

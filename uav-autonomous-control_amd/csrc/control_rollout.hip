@@ -734,7 +734,10 @@ control_rollout_kernel(const VehK V, const double *__restrict__ traj, const int6
     }
     if (LOGGING && late_handover && K > 0) lds_barrier();      // the last slab
 
-    if (!POLY && nrows > 0) row_wait(nxt);          // nothing may stay in flight into these registers
+    // nothing may stay in flight into these registers.  UNCONDITIONAL (not `if (nrows > 0)`, the mask the loads were issued under):
+    // the build check follows the control-flow graph and cannot know that a skipped wait belongs to a skipped issue -- every path
+    // from an issue site to the next pass or to the end of the kernel must cross a wait (a wave without rows waits for nothing)
+    if (!POLY) row_wait(nxt);
     if (POLY && ADMA) plan_loads_wait(srows_nx);    // ... nor into this wave's coefficient tile (the next pass, or nobody, owns it)
     if (live) {
     state[0 * sB + b] = px; state[1 * sB + b] = py; state[2 * sB + b] = pz;

@@ -520,9 +520,17 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
                            int64_t traj_capacity_rows, double *yaw, double *first_yaw) {
     UAVAC_ENTER(ctx);
     if (int rc = check_plan_args(ctx, wp, B, m)) return rc;
-    if (!times || !seg_rows || !row_offsets || !coeffs || !traj) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (!times || !seg_rows || !row_offsets || !coeffs) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
     if (!std::isfinite(velocity) || !std::isfinite(dt)) return uavac_fail(ctx, UAVAC_ENONFINITE, "non-finite velocity or dt");
     if (!(velocity > 0.0) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "velocity and dt must be > 0");
+    if (!traj) {
+        // Rows-free chain: no row buffer, hence nothing to refuse -- times, row counts and offsets go straight into the caller's
+        // arrays; the one value of the sampler a plan-fed rollout needs comes from the first-heading kernel.
+        if (yaw) return uavac_fail(ctx, UAVAC_EINVAL, "a dense yaw column needs the rows: traj is NULL");
+        if (int rc = uavac_launch_row_counts(ctx, wp, B, m, velocity, dt, times, seg_rows, row_offsets)) return rc;
+        if (int rc = uavac_launch_solve_bt(ctx, wp, times, B, m, coeffs, status)) return rc;
+        return first_yaw ? uavac_launch_first_yaw(ctx, coeffs, seg_rows, nullptr, B, m, dt, first_yaw) : UAVAC_OK;
+    }
     if (traj_capacity_rows < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative capacity");
     // The whole chain enqueued from here: nothing returns to the caller (or to an interpreter) between the launches.
     // Times, row counts and offsets go to ctx scratch first; whether the plan fits the caller's row buffer is only known on
@@ -555,6 +563,15 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
     x.first_yaw = first_yaw;
     x.capacity_rows = traj_capacity_rows;         // the sampler refuses (flag 2) instead of overrunning the buffer
     return uavac_launch_sample(ctx, coeffs, seg_rows_s, row_offsets_s, B, m, dt, traj, x);
+}
+
+int uavac_minsnap_first_yaw_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *seg_offsets, int B,
+                                int m, double dt, double *first_yaw) {
+    UAVAC_ENTER(ctx);
+    if (int rc = check_plan_args(ctx, coeffs, B, m)) return rc;
+    if (!seg_rows || !first_yaw) return uavac_fail(ctx, UAVAC_EINVAL, "null pointer");
+    if (!std::isfinite(dt) || !(dt > 0.0)) return uavac_fail(ctx, UAVAC_EINVAL, "dt must be finite and > 0");
+    return uavac_launch_first_yaw(ctx, coeffs, seg_rows, seg_offsets, B, m, dt, first_yaw);
 }
 
 int uavac_minsnap_row_offsets_dev(uavac_ctx *ctx, const int32_t *seg_rows, int B, int m, int64_t *row_offsets) {

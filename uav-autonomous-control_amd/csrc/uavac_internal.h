@@ -197,6 +197,9 @@ int uavac_launch_sample(uavac_ctx *ctx, const double *coeffs, const int32_t *seg
 int uavac_launch_sample_stream(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *row_offsets, int B,
                                int m, double dt, double *traj, const SampleExtras &x, int waves, int group);
 int uavac_launch_yaw_scan(uavac_ctx *ctx, const double *velocities, const int64_t *offsets, int B, double *yaws);
+// first_yaw [B] without the rows (minsnap_first_yaw.hip): what the sampler writes there, from the coefficients and row counts alone
+int uavac_launch_first_yaw(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *seg_offsets, int B, int m,
+                           double dt, double *first_yaw);
 int uavac_launch_state_init(uavac_ctx *ctx, const VehK &V, const double *positions, int B, int hover, double *state,
                             int32_t *istate);
 // What the rollout needs to evaluate target rows itself instead of reading them (control_rollout.hip, POLY)

@@ -81,8 +81,24 @@ def check_rollout_registers(obj: str = None):
     return counts
 
 
-def _disassemble(obj: str):
-    """{kernel name: [instruction text]} of the gfx950 code object inside `obj`, or None when it or the LLVM tools are missing."""
+class Ins(str):
+    """One instruction of a disassembled kernel: its text (the str itself), its address and, for a branch, the address it may go to."""
+    addr = None
+    target = None
+
+    def __new__(cls, text, addr=None, target=None):
+        self = super().__new__(cls, text)
+        self.addr, self.target = addr, target
+        return self
+
+
+_BRANCH = ("s_cbranch", "s_branch")
+_INDIRECT = ("s_setpc", "s_swappc", "s_call", "s_rfe", "s_cbranch_g_fork", "s_cbranch_i_fork", "s_cbranch_join")
+
+
+def _disassemble_cfg(obj: str):
+    """{kernel name: [Ins]} of the gfx950 code object inside `obj` -- instruction text with its address and branch target, which is
+    what a check needs to follow the control flow -- or None when the object file or the LLVM tools are missing."""
     objdump = os.path.join(LLVM_BIN, "llvm-objdump")
     if not (os.path.exists(obj) and os.path.exists(objdump)):
         return None
@@ -95,16 +111,50 @@ def _disassemble(obj: str):
                               text=True).stdout
     finally:
         shutil.rmtree(tmp)
-    kernels, cur = {}, None
+    kernels, cur, base = {}, None, 0
     for line in text.splitlines():
-        head = re.match(r"[0-9a-f]+ <([^>]+)>:", line)
+        head = re.match(r"([0-9a-f]+) <([^>]+)>:", line)
         if head:
-            cur = kernels.setdefault(head.group(1), [])
+            base = int(head.group(1), 16)
+            cur = kernels.setdefault(head.group(2), [])
         elif cur is not None:
-            ins = line.split("//")[0].strip()
-            if ins and not ins.endswith(":"):
-                cur.append(ins)
+            code, _, note = line.partition("//")
+            ins = code.strip()
+            if not ins or ins.endswith(":"):
+                continue
+            at = re.match(r"\s*([0-9A-Fa-f]+):", note)
+            to = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$", note) if ins.startswith(_BRANCH) else None
+            if ins.startswith(_BRANCH) and to is None and re.search(r"<[^>+]+>\s*$", note):
+                to_addr = base                                            # a branch to the kernel's first instruction
+            else:
+                to_addr = base + int(to.group(1), 16) if to else None
+            cur.append(Ins(ins, int(at.group(1), 16) if at else None, to_addr))
     return kernels
+
+
+def _disassemble(obj: str):
+    """{kernel name: [instruction text]}: `_disassemble_cfg` for the checks that read straight-line code."""
+    return _disassemble_cfg(obj)
+
+
+def _successors(ins):
+    """Successor indices of every instruction of a kernel (fall-through and branch targets); raises on a branch the disassembly
+    gives no target for."""
+    index = {x.addr: i for i, x in enumerate(ins) if getattr(x, "addr", None) is not None}
+    succ = []
+    for i, x in enumerate(ins):
+        if x.startswith("s_endpgm"):
+            succ.append(())
+        elif x.startswith(_INDIRECT):
+            raise RuntimeError(f"indirect control flow ('{x}'): the check cannot follow it")
+        elif x.startswith(_BRANCH):
+            t = index.get(getattr(x, "target", None))
+            if t is None:
+                raise RuntimeError(f"branch '{x}' without a known target")
+            succ.append((t,) if x.startswith("s_branch") else (i + 1, t))
+        else:
+            succ.append((i + 1,))
+    return [tuple(j for j in s if j < len(ins)) for s in succ]
 
 
 def _vregs(text: str):
@@ -120,11 +170,13 @@ _ROW_LOAD = re.compile(r"global_load_dwordx4 v\[(\d+):(\d+)\], (v\[\d+:\d+\]), o
 def check_row_prefetch(obj: str = None):
     """The row-fed rollout kernels prefetch a trajectory row with loads the compiler does not know to be in flight (inline asm,
     control_rollout.hip row_issue / row_wait).  That is only right while the loads land in the very registers row_wait() hands
-    on: for every row-fed variant, (1) every group of five row loads writes the same twenty registers, (2) nothing else writes or
-    reads one of them unless -- walking back through the code -- an `s_waitcnt vmcnt(0)` comes before any row load (code ahead of
-    the first row load is free to use them).  Raises RuntimeError otherwise; returns the number of variants checked, None when
-    the object file cannot be read."""
-    kernels = _disassemble(obj or os.path.join(PKG, "build", "control_rollout.o"))
+    on: for every row-fed variant, (1) every group of five row loads writes the same twenty registers, (2) no other instruction
+    reads or writes one of them at a point that a row load can reach without passing an `s_waitcnt vmcnt(0)` -- decided on the
+    kernel's CONTROL-FLOW GRAPH (branch targets from the disassembly; a forward may-analysis "row loads possibly in flight"), not
+    on the linear layout: a wait that sits in a block the executed path branches over proves nothing (round-5 advice).  Code
+    that no row load reaches (ahead of the first one) is free to use the registers.  Raises RuntimeError otherwise; returns the
+    number of variants checked, None when the object file cannot be read."""
+    kernels = _disassemble_cfg(obj or os.path.join(PKG, "build", "control_rollout.o"))
     if kernels is None:
         return None
     checked, bad = 0, []
@@ -147,13 +199,29 @@ def check_row_prefetch(obj: str = None):
             bad.append((name[:90], f"row-load groups: {[(i, sorted(g)[:1], len(g)) for i, g in groups]}"))
             continue
         dest, inside = groups[0][1], {j for i, _ in groups for j in range(i, i + 5)}
+        try:
+            succ = _successors(ins)
+        except RuntimeError as exc:
+            bad.append((name[:90], str(exc)))
+            continue
+        # in_flight[j]: some path reaches instruction j with a row load issued and no vmcnt(0) wait since
+        in_flight = [False] * (len(ins) + 1)
+        work = []
+        for j in inside:
+            for k in succ[j]:
+                if not in_flight[k]:
+                    in_flight[k] = True
+                    work.append(k)
+        while work:
+            j = work.pop()
+            if j >= len(ins) or j in inside or re.match(r"s_waitcnt vmcnt\(0\)", ins[j]):
+                continue                            # (a row load's own successors are seeded above; a wait ends the flight)
+            for k in succ[j]:
+                if not in_flight[k]:
+                    in_flight[k] = True
+                    work.append(k)
         for j, x in enumerate(ins):
-            if j in inside or not (_vregs(x) & dest):
-                continue
-            k = j - 1
-            while k >= 0 and k not in inside and not re.match(r"s_waitcnt vmcnt\(0\)", ins[k]):
-                k -= 1
-            if k in inside:
+            if j not in inside and in_flight[j] and (_vregs(x) & dest):
                 bad.append((name[:90], f"'{x}' touches a row register while the row loads may be in flight"))
                 break
     if bad or checked < 16:
@@ -208,6 +276,60 @@ def check_no_diagnostics(lib_path: str = None):
     if diag:
         raise RuntimeError(f"{lib_path} exports diagnostic symbols {diag}: it was built with a UAVAC_DIAG_* define")
     return True
+
+
+def library_sha256(lib_path: str = None) -> str:
+    import hashlib
+    with open(lib_path or os.path.join(PKG, "lib", "libuavac.so"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
+STAMP = os.path.join(PKG, "lib", "libuavac.buildcheck.json")
+
+
+def run_all(verbose: bool = False, write_stamp: bool = True) -> dict:
+    """EVERY build check, for every place that builds the library (`__graft_entry__.build()`, the autobuild of
+    `uav_ac._native.lib()`, `make check`): the rollout kernels' register budget, the row prefetch and the sampler's heading
+    prefetch in the disassembly, no diagnostic symbol, the planning kernels' budgets.  A check that cannot run (no object files,
+    no LLVM tools) is a FAILURE here: the output-only asm operands of row_issue / HeadingFromLds are only as safe as these
+    checks, so a build they did not see must not pass for one they did.  Raises RuntimeError; on success writes
+    lib/libuavac.buildcheck.json -- the library's sha256, its uavac_build_info() and the compiler the checks saw -- which
+    travels with the library (tests/test_gpu_round6.py compares it with the library the GPU process loaded)."""
+    import ctypes
+    import json
+    result = {}
+    steps = (("rollout_registers", check_rollout_registers, lambda r: f"{len(r)} rollout kernels, at most {max(v for _, v, _ in r)} VGPRs, no spills"),
+             ("row_prefetch", check_row_prefetch, lambda r: f"row prefetch of {r} row-fed rollout kernels verified on the control-flow graph of the disassembly"),
+             ("heading_prefetch", check_heading_prefetch, lambda r: f"{r} coefficient prefetches of the streaming sampler verified in the disassembly"),
+             ("no_diagnostics", check_no_diagnostics, lambda r: "no diagnostic symbol exported"),
+             ("planning_registers", check_planning_registers, lambda r: f"{len(r)} sampler / solve kernels inside their register budgets, no spills"))
+    for key, fn, say in steps:
+        r = fn()
+        if r is None:
+            raise RuntimeError(f"build check '{key}' could not run (object files under {PKG}/build or the LLVM tools under {LLVM_BIN} are "
+                               "missing): the library would ship unchecked")
+        result[key] = len(r) if isinstance(r, list) else r
+        if verbose:
+            print(f"build: {say(r)}")
+    lib_path = os.path.join(PKG, "lib", "libuavac.so")
+    fn = ctypes.CDLL(lib_path).uavac_build_info
+    fn.restype = ctypes.c_char_p
+    stamp = {"library_sha256": library_sha256(lib_path), "build_info": fn().decode(), "checked_with": compiler_version(), "checks": result}
+    if write_stamp:
+        tmp = STAMP + f".tmp.{os.getpid()}"
+        with open(tmp, "w") as fh:
+            json.dump(stamp, fh, indent=1)
+        os.replace(tmp, STAMP)
+    return stamp
+
+
+def read_stamp():
+    """The record `run_all` left beside the library, or None."""
+    import json
+    if not os.path.exists(STAMP):
+        return None
+    with open(STAMP) as fh:
+        return json.load(fh)
 
 
 def compiler_version() -> str:

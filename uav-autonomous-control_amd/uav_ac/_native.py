@@ -20,7 +20,7 @@ OK, EINVAL, ENONFINITE, EHIP, ESINGULAR, ENOMEM, ECOMM, ETOOLCHAIN = 0, -1, -2, 
 COMM_ID_BYTES = 128
 MAX_SEGMENTS = 64
 TRAJ_COLS, STATE_ROWS, ISTATE_ROWS, CMD_COLS = 11, 30, 4, 12
-VERSION = 300
+VERSION = 310
 GROUND_IN_CONTACT, GROUND_TAKEN_OFF, GROUND_HIT_AFTER_TAKEOFF = 1, 2, 4       # istate row 3 (include/uavac.h)
 
 
@@ -80,6 +80,7 @@ _SIGNATURES = {
     "uavac_minsnap_sample_derivs_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]),
     "uavac_minsnap_plan_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P, _P,
                                           C.c_int64, _P, _P]),
+    "uavac_minsnap_first_yaw_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P]),
     "uavac_minsnap_row_offsets_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "uavac_minsnap_row_offsets_ragged_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "uavac_minsnap_plan_ragged": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, C.c_int64]),
@@ -162,6 +163,17 @@ def lib() -> C.CDLL:
                 subprocess.run(["make", "-C", pkg, "-j4"], check=True, capture_output=True)
             except Exception as exc:
                 raise UavacError(EHIP, f"{LIB_PATH} not built and `make -C {pkg}` failed: {exc}") from exc
+            # a library built here is CHECKED here, like one built by __graft_entry__.build(): register budgets and the
+            # hand-placed prefetches in the disassembly (the compiler on this box may not be the one the checks last saw)
+            from . import _buildcheck
+            try:
+                _buildcheck.run_all()
+            except Exception as exc:
+                try:
+                    os.replace(LIB_PATH, LIB_PATH + ".failed-buildcheck")      # never load (or leave for the next process) an unchecked build
+                except OSError:
+                    pass
+                raise UavacError(EHIP, f"{LIB_PATH} was built but FAILED its build checks and was set aside: {exc}") from exc
         try:                                   # share torch's HIP runtime when torch is in the process
             import torch  # noqa: F401
         except Exception:                      # pragma: no cover - torch is plumbing, not a requirement of the ABI

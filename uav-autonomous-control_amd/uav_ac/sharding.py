@@ -1,0 +1,141 @@
+"""How a job of B independent missions is cut over the ranks of one node: contiguous mission-index
+blocks, no data-path collective; and how large the block of the final gather's root should be so that it finishes with
+its peers -- from what a shard of n missions costs on the GPU at hand (`measure_tick_table`).  No reference counterpart
+(upstream plans and flies one mission per process, uav_ac/main.py:87-120)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_sizes(B: int, world: int, root_share: float = None, root: int = 0):
+    """Missions per rank: contiguous blocks in rank order.  Equal blocks (sizes differ by at most one) unless
+    `root_share` is given: then rank `root` -- the rank the trajectories are gathered to -- takes round(root_share * B)
+    missions (at least 1 when B >= world) and the other ranks share the rest equally.  The root of the final gather has
+    extra work (it re-samples or receives everybody's rows while it flies), so its block is made smaller:
+    `balanced_root_share` says by how much."""
+    B, world = int(B), int(world)
+    if world < 1 or B < 0 or not (0 <= root < world):
+        raise ValueError("need world >= 1, B >= 0, 0 <= root < world")
+    if root_share is None or world == 1:
+        base, rem = divmod(B, world)
+        return [base + (1 if r < rem else 0) for r in range(world)]
+    if not (0.0 <= root_share <= 1.0):
+        raise ValueError("root_share is a fraction of the batch")
+    n_root = int(round(root_share * B))
+    n_root = max(min(n_root, B), 1 if B >= world else 0)
+    n_root = min(n_root, B - (world - 1) if B >= world else n_root)     # every peer keeps at least one mission
+    base, rem = divmod(B - n_root, world - 1)
+    peers = [base + (1 if i < rem else 0) for i in range(world - 1)]
+    return peers[:root] + [n_root] + peers[root:]
+
+
+def shard_bounds(B: int, rank: int, world: int, root_share: float = None, root: int = 0):
+    """Contiguous mission-index block [lo, hi) of this rank: no data-path collective needed.  Sizes: `shard_sizes`."""
+    sizes = shard_sizes(B, world, root_share, root)
+    lo = sum(sizes[:rank])
+    return lo, lo + sizes[rank]
+
+
+# One MI355X, measured (round 4: profiles/r04_config_sweep.jsonl, tools/rollout_ab.py, m = 8 .. 12): UAVs in flight on the GPU,
+# us per logged tick, ms of the planning chain per 1 000 missions.  A FALLBACK: `measure_tick_table` measures the same three
+# columns on the GPU at hand in a few tens of milliseconds, and `bench.py --gpus N` does so before it cuts the shards.
+DEFAULT_TICK_TABLE = ((4096, 0.787, 0.027), (16384, 0.792, 0.0180), (24576, 0.843, 0.0170), (32768, 0.857, 0.0163), (35237, 0.876, 0.0163),
+                      (49152, 1.019, 0.0163), (65536, 1.262, 0.0163))
+
+
+def measure_tick_table(engine: "Engine", segments: int, sizes, velocity: float = 3.0, dt: float = 0.01, ticks: int = 2500,
+                       launches: int = 2, seed: int = 7):
+    """What a shard of n missions costs on THIS GPU, for every n in `sizes`: [(n, us per logged tick, ms of the planning chain
+    per 1 000 missions)].  Synthetic missions of the SURVEY 8(d) shape, planned once more after a warm-up, then `launches`
+    logged launches of `ticks` ticks (the first is thrown away; long launches, as the job itself flies them: a launch boundary
+    costs 50-80 us below a full chip).  A few tens of milliseconds per size."""
+    torch = engine._torch
+    rng = np.random.default_rng(seed)
+    table = []
+    for n in sorted({int(x) for x in sizes if int(x) > 0}):
+        d = rng.standard_normal((n, segments, 3)) * np.array([1, 1, 0.25])
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        w0 = np.concatenate([rng.uniform(0, 24, (n, 1, 1)), rng.uniform(0, 14, (n, 1, 1)), np.full((n, 1, 1), -3.0)], axis=2)
+        wps = np.concatenate([w0, w0 + np.cumsum(rng.uniform(2.5, 3.5, (n, segments, 1)) * d, axis=1)], axis=1)
+        plan = engine.plan(wps, velocity, dt)
+        fleet = engine.fleet(plan)
+        pitch = -(-n // 16) * 16
+        log = torch.empty((ticks, 13, pitch), dtype=torch.float64, device=engine.device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        engine.replan(plan)
+        ev[0].record()
+        engine.replan(plan)
+        ev[1].record()
+        fleet.reset()
+        fleet.rollout(ticks, state_log=log, log_pitch=pitch)
+        ev[2].record()
+        for _ in range(launches - 1):
+            fleet.rollout(ticks, state_log=log, log_pitch=pitch)
+        ev[3].record()
+        torch.cuda.synchronize(engine.device)
+        table.append((n, ev[2].elapsed_time(ev[3]) * 1e3 / ((launches - 1) * ticks), ev[0].elapsed_time(ev[1]) / (n / 1000.0)))
+        del plan, fleet, log
+    return table
+
+
+def candidate_shard_sizes(B: int, world: int):
+    """The shard sizes worth measuring before `balanced_root_share` cuts a B-mission job over `world` ranks: half an equal block
+    (about what the root ends up with), an equal block, and a peer's block when the root takes next to nothing."""
+    eq = max(1, B // world)
+    return sorted({max(1, eq // 2), eq, min(B, -(-B // max(1, world - 1)))})
+
+
+def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_segment: float = 112.9,
+                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 5.8e12, tick_table=None) -> float:
+    """The share of a B-mission job the gather's root should take so that it finishes with its peers (BASELINE configs[3]).
+
+    A PROJECTION from one-GPU measurements, not a measurement of N GPUs: a peer with n missions plans them and flies `ticks`
+    logged ticks -- both read off `tick_table` = [(n, us per logged tick, ms of planning per 1 000 missions)], as
+    `measure_tick_table` returns it for the GPU at hand (default: `DEFAULT_TICK_TABLE`, round-4 numbers of one MI355X), linear
+    between its points, flat below the first, proportional to n above the last; the root does the same for its own block and,
+    beside it, receives the peers' plans and re-samples their rows (plan gather) or receives the rows themselves -- either way
+    its HBM takes the peers' rows on top of its own log (104 B per UAV tick), so its time is the larger of its flight and of
+    (log + all rows) / the HBM write rate.  Bisection on the share."""
+    if world <= 1:
+        return 1.0
+    table = sorted((float(n), float(t), float(p)) for n, t, p in (tick_table or DEFAULT_TICK_TABLE))
+    if not table or any(t <= 0 or p <= 0 or n <= 0 for n, t, p in table):
+        raise ValueError("tick_table: [(missions, us per tick, ms of planning per 1000 missions)], all positive")
+    row_bytes = 88.0 * rows_per_segment * segments                       # per mission
+
+    def lookup(n, col):
+        if n <= table[0][0]:
+            return table[0][col]
+        for lo_, hi_ in zip(table, table[1:]):
+            if n <= hi_[0]:
+                return lo_[col] + (hi_[col] - lo_[col]) * (n - lo_[0]) / (hi_[0] - lo_[0])
+        return table[-1][col] * (n / table[-1][0] if col == 1 else 1.0)   # a full chip walks its tiles pass after pass
+
+    def own(n):                                                          # plan + flight of n missions, seconds
+        return lookup(n, 2) * 1e-3 * n / 1000.0 + ticks * lookup(n, 1) * 1e-6
+
+    def root_time(s):
+        n = s * B
+        stream = (n * ticks * 104.0 + B * row_bytes) / hbm_write_bytes_per_s
+        return max(own(n), stream) if plan_gather else own(n) + (B - n) * row_bytes / (7 * 153e9 * min(1.0, (world - 1) / 7.0))
+
+    def peer_time(s):
+        return own((1.0 - s) * B / (world - 1))
+
+    lo, hi = 0.0, 1.0 / world
+    if root_time(hi) <= peer_time(hi):
+        return hi                                                        # equal blocks already balance
+    for _ in range(50):
+        mid = 0.5 * (lo + hi)
+        if root_time(mid) > peer_time(mid):
+            hi = mid
+        else:
+            lo = mid
+    return 0.5 * (lo + hi)
+
+
+def gather_layout(counts, dst: int):
+    """Where every rank's block lands in the root's buffer: row offsets (world + 1,) and the peers that send.
+    Shared by the RCCL path (whose C side derives the same offsets from the same counts) and the host rehearsal."""
+    offs = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
+    return offs, [r for r in range(len(counts)) if r != dst and counts[r] > 0]
