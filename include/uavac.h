@@ -588,6 +588,19 @@ int uavac_gather_rows_dev(uavac_ctx *ctx, void *nccl_comm, const double *rows, i
 int uavac_gather_plan_dev(uavac_ctx *ctx, void *nccl_comm, const double *coeffs, const double *times,
                           const int32_t *seg_rows, int64_t n_segments, const int64_t *seg_counts, int root,
                           double *coeffs_out, double *times_out, int32_t *seg_rows_out);
+/* One PART of uavac_gather_plan_dev, for a gather that is PIPELINED with the root's re-sampling: segments
+ * [part_first[r], part_first[r] + part_counts[r]) of rank r's block travel and land on the root where the gather of the whole
+ * blocks puts them (segment offset sum(seg_counts[:r]) + part_first[r] of the *_out arrays).  The pointers are those of the rank's
+ * WHOLE block / of the root's whole output arrays; an array travels when its pointer is non-NULL, on every rank alike (the root:
+ * when its *_out pointer is non-NULL) -- e.g. first times + seg_rows of the whole blocks (12 B per segment: the root can then lay
+ * out every mission's rows), then the coefficients (192 B per segment) in a few parts, each of which the root samples while the
+ * next one arrives.  seg_counts / part_first / part_counts [world] are HOST arrays, the same on every rank.  Enqueued on the ctx
+ * stream like the other gathers; RCCL executes the operations of one communicator in the order they were issued, whatever
+ * streams they were issued on.  (No reference counterpart.) */
+int uavac_gather_plan_part_dev(uavac_ctx *ctx, void *nccl_comm, const double *coeffs, const double *times,
+                               const int32_t *seg_rows, const int64_t *seg_counts, const int64_t *part_first,
+                               const int64_t *part_counts, int root, double *coeffs_out, double *times_out,
+                               int32_t *seg_rows_out);
 /* NCCL_VERSION_CODE of the rccl.h this library was built with, and ncclGetVersion() of the RCCL the process has
  * mapped (in a Python process: the one bundled with torch).  uavac_comm_init_rank refuses a different major version
  * or a runtime older than 2.10; only entry points stable since then are used, so the minor versions may differ. */

@@ -100,7 +100,9 @@ int main(void) {
     EXPECT(uavac_comm_shape(NULL, NULL, &world, &rank) == UAVAC_EINVAL && uavac_gather_counts(NULL, NULL, 1, i64) == UAVAC_EINVAL);
     EXPECT(uavac_gather_rows_dev(NULL, NULL, d, 1, 11, i64, 0, d) == UAVAC_EINVAL);
     EXPECT(uavac_gather_plan_dev(NULL, NULL, d, d, i32, 1, i64, 0, d, d, i32) == UAVAC_EINVAL);
+    EXPECT(uavac_gather_plan_part_dev(NULL, NULL, d, d, i32, i64, i64, i64, 0, d, d, i32) == UAVAC_EINVAL);
+    EXPECT(uavac_minsnap_first_yaw_dev(NULL, d, i32, NULL, 1, 1, 0.01, d) == UAVAC_EINVAL);
     EXPECT(uavac_comm_finish(NULL, NULL) == UAVAC_EINVAL && uavac_comm_loopback_dev(NULL, NULL, d, d, 1) == UAVAC_EINVAL);
-    printf("asan driver: %d entry points answered a GPU-less host as documented\n", 72);
+    printf("asan driver: %d entry points answered a GPU-less host as documented\n", 74);
     return 0;
 }

@@ -110,6 +110,20 @@ def test_shard_bounds_partition_the_batch():
         shard_sizes(10, 2, 1.5)
 
 
+def test_pipeline_part_bounds():
+    """sharding.part_bounds: the mission boundaries of a pipelined plan gather's parts -- pure arithmetic every rank repeats for
+    every rank: monotone, from 0 to n, small blocks degenerate to empty parts, shares are validated."""
+    from uav_ac.sharding import PIPELINE_SHARES, part_bounds
+    assert PIPELINE_SHARES[-1] == 1.0 and part_bounds(36864) == [0, 2304, 9216, 18432, 36864]
+    for n in (0, 1, 2, 5, 15, 16, 17, 8191, 262144):
+        b = part_bounds(n)
+        assert b[0] == 0 and b[-1] == n and len(b) == len(PIPELINE_SHARES) + 1 and all(x <= y for x, y in zip(b, b[1:]))
+    assert part_bounds(10, (0.5, 1.0)) == [0, 5, 10] and part_bounds(7, (1.0,)) == [0, 7]
+    for bad in ((), (0.5,), (0.5, 0.5, 1.0), (0.7, 0.2, 1.0), (0.0, 1.0)):
+        with pytest.raises(ValueError):
+            part_bounds(10, bad)
+
+
 def _build_c_demo(tmp_path):
     import subprocess
     from conftest import PKG, REPO

@@ -225,3 +225,76 @@ def test_the_loaded_library_is_the_one_the_build_checks_saw(eng):
     if os.path.exists(os.path.join(PKG, "build", "control_rollout.o")) and os.path.exists(os.path.join(_buildcheck.LLVM_BIN, "llvm-objdump")):
         again = _buildcheck.run_all(write_stamp=False)
         assert again["library_sha256"] == stamp["library_sha256"] and again["checks"] == stamp["checks"]
+
+
+def test_sampling_by_ranges_in_any_order_leaves_the_same_rows(eng):
+    """Engine.sample_range: missions [b0, b1) of a plan through the same sampler on offset pointers (row offsets are absolute).
+    Any cover of the batch, in any order, with empty ranges in between, writes the rows, the first headings and a dense yaw
+    column of one sample(plan) bit for bit -- what the root of a pipelined plan gather relies on."""
+    import torch
+    from oracle import minsnap_oracle as mo
+    rng = np.random.default_rng(61)
+    for B, m, dense in ((3000, 8, False), (777, 12, True), (5, 2, False)):
+        plan = eng.plan(mo.synthetic_missions(B, m), 3.0, 0.01, dense_yaw=dense)
+        want = {k: getattr(plan, k).clone() for k in ("traj", "first_yaw") + (("yaw",) if dense else ())}
+        for waves in (4, 1):                                      # the chunk-streaming sampler and the one-wave-per-mission one
+            eng.ctx.set_option("sampler_waves", waves)
+            for k in want:
+                getattr(plan, k).fill_(float("nan"))
+            cuts = sorted({0, B} | {int(x) for x in rng.integers(0, B + 1, size=6)})
+            ranges = list(zip(cuts, cuts[1:])) + [(cuts[1], cuts[1])]
+            for i in rng.permutation(len(ranges)):
+                eng.sample_range(plan, *ranges[int(i)])
+            for k, v in want.items():
+                assert torch.equal(getattr(plan, k), v), (B, m, waves, k)
+        eng.ctx.set_option("sampler_waves", 4)
+    with pytest.raises(ValueError):
+        eng.sample_range(plan, 3, 2)
+    with pytest.raises(ValueError):
+        eng.sample_range(eng.plan(mo.synthetic_missions(4, 2), 3.0, 0.01, rows=False), 0, 4)
+
+
+def test_pipelined_plan_gather_world1_equals_the_one_shot_gather(eng):
+    """RcclComm.gather_plan(parts=...) at world 1 over RCCL behind the C ABI: durations and row counts first, the coefficients in
+    parts on a transfer stream (uavac_gather_plan_part_dev: here the root's own block, device-to-device), every part sampled
+    behind its event.  Same Plan as the one-shot gather, bit for bit, from a full and from a rows-free plan, with the default
+    shares and with others; part arguments are validated before anything is enqueued."""
+    import torch
+    from uav_ac import _native as nat
+    from uav_ac.fleet import RcclComm
+    from uav_ac.sharding import PIPELINE_SHARES, part_bounds
+    from oracle import minsnap_oracle as mo
+    buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+    eng.ctx.call("uavac_comm_unique_id", buf)
+    comm = RcclComm(eng, unique_id=bytes(buf.raw), world=1, rank=0)
+    try:
+        wps = mo.synthetic_missions(2500, 8)
+        full = eng.plan(wps, 3.0, 0.01)
+        free = eng.plan(wps, 3.0, 0.01, rows=False)
+        ref, counts = comm.gather_plan(full, dst=0)
+        assert counts == [full.total_rows] and torch.equal(ref.traj, full.traj)
+        side = torch.cuda.Stream(device=eng.device)
+        known = comm.plan_counts(free)
+        assert known == ([2500 * 8], [full.total_rows])
+        for plan, parts, stream, kc in ((full, True, None, None), (free, True, side, known), (free, (0.5, 1.0), None, None),
+                                        (free, (0.001, 0.002, 1.0), side, known)):
+            got, cnt = comm.gather_finish(comm.gather_plan_begin(plan, dst=0, stream=stream, parts=parts, known_counts=kc))
+            torch.cuda.synchronize()
+            assert cnt == counts
+            for k in ("traj", "coeffs", "times", "seg_rows", "row_offsets", "first_yaw"):
+                assert torch.equal(getattr(got, k), getattr(ref, k)), (parts, k)
+        assert part_bounds(2500, PIPELINE_SHARES) == [0, 156, 625, 1250, 2500]
+        one = (C.c_int64 * 1)
+        args = lambda first, count: ("uavac_gather_plan_part_dev", comm._h, C.c_void_p(free.coeffs.data_ptr()), None, None,      # noqa: E731
+                                     one(20000), one(first), one(count), 0, C.c_void_p(ref.coeffs.data_ptr()), None, None)
+        for first, count in ((19999, 2), (-1, 1)):
+            with pytest.raises(nat.UavacError) as e:
+                eng.ctx.call(*args(first, count))
+            assert e.value.code == nat.EINVAL
+        with pytest.raises(nat.UavacError):                       # the root's own arrays and its outputs must name the same arrays
+            eng.ctx.call("uavac_gather_plan_part_dev", comm._h, C.c_void_p(free.coeffs.data_ptr()), None, None, one(20000), one(0), one(8),
+                         0, None, C.c_void_p(ref.times.data_ptr()), None)
+        with pytest.raises(ValueError):
+            comm.gather_plan(eng.plan_ragged([w[:3] for w in wps[:4]], 3.0, 0.01), parts=True)
+    finally:
+        comm.close()

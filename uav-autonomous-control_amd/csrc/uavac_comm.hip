@@ -164,6 +164,50 @@ int uavac_gather_rows_dev(uavac_ctx *ctx, void *nccl_comm, const double *rows, i
     return UAVAC_OK;                    // enqueued on the ctx stream; uavac_comm_finish() synchronises and checks
 }
 
+// Segments [first[r], first[r] + count[r]) of every rank's block (whose sizes are seg_counts) travel to the root and land where
+// the gather of the whole blocks puts them.  An array travels when it is non-NULL (the caller keeps that consistent over ranks).
+static int gather_plan_ranges(uavac_ctx *ctx, ncclComm_t comm, int world, int rank, const double *coeffs, const double *times,
+                              const int32_t *seg_rows, const int64_t *seg_counts, const int64_t *first, const int64_t *count, int root,
+                              double *coeffs_out, double *times_out, int32_t *seg_rows_out) {
+    const size_t f = (size_t)first[rank], n = (size_t)count[rank];
+    if (rank == root) {
+        std::vector<size_t> off((size_t)world + 1, 0);
+        for (int r = 0; r < world; ++r) off[r + 1] = off[r] + (size_t)seg_counts[r];
+        const size_t o = off[rank] + f;
+        if (n > 0) {                                                // the root's own block: device-to-device copies
+            if (coeffs && coeffs_out + o * 24 != coeffs + f * 24)
+                UAVAC_HIP(ctx, hipMemcpyAsync(coeffs_out + o * 24, coeffs + f * 24, n * 24 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (times_out && times && times_out + o != times + f)
+                UAVAC_HIP(ctx, hipMemcpyAsync(times_out + o, times + f, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (seg_rows && seg_rows_out + o != seg_rows + f)
+                UAVAC_HIP(ctx, hipMemcpyAsync(seg_rows_out + o, seg_rows + f, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        // one grouped launch for all peers and all arrays: the receives of different peers run concurrently, one per
+        // direct xGMI link into the root
+        UAVAC_NCCL(ctx, ncclGroupStart());
+        ncclResult_t res = ncclSuccess;
+        for (int r = 0; r < world && res == ncclSuccess; ++r) {
+            if (r == root || count[r] == 0) continue;
+            const size_t c = (size_t)count[r], at = off[r] + (size_t)first[r];
+            if (coeffs_out) res = ncclRecv(coeffs_out + at * 24, c * 24, ncclDouble, r, comm, ctx->stream);
+            if (res == ncclSuccess && times_out) res = ncclRecv(times_out + at, c, ncclDouble, r, comm, ctx->stream);
+            if (res == ncclSuccess && seg_rows_out) res = ncclRecv(seg_rows_out + at, c, ncclInt32, r, comm, ctx->stream);
+        }
+        if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclRecv", res); }
+        UAVAC_NCCL(ctx, ncclGroupEnd());
+    } else if (n > 0) {
+        UAVAC_NCCL(ctx, ncclGroupStart());
+        ncclResult_t res = ncclSuccess;
+        if (coeffs) res = ncclSend(coeffs + f * 24, n * 24, ncclDouble, root, comm, ctx->stream);
+        if (res == ncclSuccess && times) res = ncclSend(times + f, n, ncclDouble, root, comm, ctx->stream);
+        if (res == ncclSuccess && seg_rows) res = ncclSend(seg_rows + f, n, ncclInt32, root, comm, ctx->stream);
+        if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclSend", res); }
+        UAVAC_NCCL(ctx, ncclGroupEnd());
+    }
+    UAVAC_HIP(ctx, hipGetLastError());
+    return UAVAC_OK;                    // enqueued on the ctx stream; uavac_comm_finish() synchronises and checks
+}
+
 int uavac_gather_plan_dev(uavac_ctx *ctx, void *nccl_comm, const double *coeffs, const double *times, const int32_t *seg_rows,
                           int64_t n_segments, const int64_t *seg_counts, int root, double *coeffs_out, double *times_out,
                           int32_t *seg_rows_out) {
@@ -178,45 +222,40 @@ int uavac_gather_plan_dev(uavac_ctx *ctx, void *nccl_comm, const double *coeffs,
         if (seg_counts[r] < 0) return uavac_fail(ctx, UAVAC_EINVAL, "negative count");
     if (seg_counts[rank] != n_segments) return uavac_fail(ctx, UAVAC_EINVAL, "seg_counts[rank] != n_segments");
     if (n_segments > 0 && (!coeffs || !seg_rows)) return uavac_fail(ctx, UAVAC_EINVAL, "null coeffs or seg_rows");
-    const size_t n = (size_t)n_segments;
     if (rank == root) {
-        std::vector<size_t> off((size_t)world + 1, 0);
-        for (int r = 0; r < world; ++r) off[r + 1] = off[r] + (size_t)seg_counts[r];
-        if (off[world] > 0 && (!coeffs_out || !seg_rows_out)) return uavac_fail(ctx, UAVAC_EINVAL, "null output on the root");
-        if (n > 0 && (times_out != nullptr) != (times != nullptr))
+        int64_t total = 0;
+        for (int r = 0; r < world; ++r) total += seg_counts[r];
+        if (total > 0 && (!coeffs_out || !seg_rows_out)) return uavac_fail(ctx, UAVAC_EINVAL, "null output on the root");
+        if (n_segments > 0 && (times_out != nullptr) != (times != nullptr))
             return uavac_fail(ctx, UAVAC_EINVAL, "times and times_out go together (on every rank, or on none)");
-        const size_t o = off[rank];
-        if (n > 0) {                                                // the root's own block: device-to-device copies
-            if (coeffs_out + o * 24 != coeffs)
-                UAVAC_HIP(ctx, hipMemcpyAsync(coeffs_out + o * 24, coeffs, n * 24 * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            if (times_out && times && times_out + o != times)
-                UAVAC_HIP(ctx, hipMemcpyAsync(times_out + o, times, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            if (seg_rows_out + o != seg_rows)
-                UAVAC_HIP(ctx, hipMemcpyAsync(seg_rows_out + o, seg_rows, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        // one grouped launch for all peers and all three arrays: the receives of different peers run concurrently, one per
-        // direct xGMI link into the root
-        UAVAC_NCCL(ctx, ncclGroupStart());
-        ncclResult_t res = ncclSuccess;
-        for (int r = 0; r < world && res == ncclSuccess; ++r) {
-            if (r == root || seg_counts[r] == 0) continue;
-            const size_t c = (size_t)seg_counts[r];
-            res = ncclRecv(coeffs_out + off[r] * 24, c * 24, ncclDouble, r, comm, ctx->stream);
-            if (res == ncclSuccess && times_out) res = ncclRecv(times_out + off[r], c, ncclDouble, r, comm, ctx->stream);
-            if (res == ncclSuccess) res = ncclRecv(seg_rows_out + off[r], c, ncclInt32, r, comm, ctx->stream);
-        }
-        if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclRecv", res); }
-        UAVAC_NCCL(ctx, ncclGroupEnd());
-    } else if (n > 0) {
-        UAVAC_NCCL(ctx, ncclGroupStart());
-        ncclResult_t res = ncclSend(coeffs, n * 24, ncclDouble, root, comm, ctx->stream);
-        if (res == ncclSuccess && times) res = ncclSend(times, n, ncclDouble, root, comm, ctx->stream);
-        if (res == ncclSuccess) res = ncclSend(seg_rows, n, ncclInt32, root, comm, ctx->stream);
-        if (res != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(ctx, "ncclSend", res); }
-        UAVAC_NCCL(ctx, ncclGroupEnd());
     }
-    UAVAC_HIP(ctx, hipGetLastError());
-    return UAVAC_OK;                    // enqueued on the ctx stream; uavac_comm_finish() synchronises and checks
+    std::vector<int64_t> zero((size_t)world, 0);
+    return gather_plan_ranges(ctx, comm, world, rank, coeffs, times, seg_rows, seg_counts, zero.data(), seg_counts, root, coeffs_out,
+                              times_out, seg_rows_out);
+}
+
+int uavac_gather_plan_part_dev(uavac_ctx *ctx, void *nccl_comm, const double *coeffs, const double *times, const int32_t *seg_rows,
+                               const int64_t *seg_counts, const int64_t *part_first, const int64_t *part_counts, int root,
+                               double *coeffs_out, double *times_out, int32_t *seg_rows_out) {
+    UAVAC_ENTER(ctx);
+    if (!nccl_comm || !seg_counts || !part_first || !part_counts) return uavac_fail(ctx, UAVAC_EINVAL, "null communicator or counts");
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    int world = 0, rank = 0;
+    if (int rc = comm_shape(ctx, comm, &world, &rank)) return rc;
+    if (root < 0 || root >= world) return uavac_fail(ctx, UAVAC_EINVAL, "root out of range");
+    for (int r = 0; r < world; ++r)
+        if (seg_counts[r] < 0 || part_first[r] < 0 || part_counts[r] < 0 || part_first[r] + part_counts[r] > seg_counts[r])
+            return uavac_fail(ctx, UAVAC_EINVAL, "a part must lie inside its rank's block");
+    if (!coeffs && !times && !seg_rows && part_counts[rank] > 0) return uavac_fail(ctx, UAVAC_EINVAL, "nothing to send");
+    if (rank == root) {
+        // what the root receives is decided by its *_out pointers; its own block must offer the same arrays
+        if (!coeffs_out && !times_out && !seg_rows_out) return uavac_fail(ctx, UAVAC_EINVAL, "null output on the root");
+        if (part_counts[rank] > 0 && ((coeffs_out != nullptr) != (coeffs != nullptr) || (times_out != nullptr) != (times != nullptr) ||
+                                      (seg_rows_out != nullptr) != (seg_rows != nullptr)))
+            return uavac_fail(ctx, UAVAC_EINVAL, "the root's own arrays and its outputs must name the same arrays");
+    }
+    return gather_plan_ranges(ctx, comm, world, rank, coeffs, times, seg_rows, seg_counts, part_first, part_counts, root, coeffs_out,
+                              times_out, seg_rows_out);
 }
 
 int uavac_comm_versions(int *built_with, int *runtime) {

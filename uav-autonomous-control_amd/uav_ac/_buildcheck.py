@@ -338,3 +338,13 @@ def compiler_version() -> str:
         return " / ".join(line.strip() for line in out.splitlines()[:2])
     except Exception:                                        # pragma: no cover
         return "unknown"
+
+
+if __name__ == "__main__":                                   # `make` (the Makefile's default target) runs this after linking
+    import sys
+    try:
+        _s = run_all(verbose=True)
+    except Exception as exc:
+        print(f"build checks FAILED: {exc}", file=sys.stderr)
+        sys.exit(1)
+    print(f"build: checks passed for library {_s['library_sha256'][:16]}")

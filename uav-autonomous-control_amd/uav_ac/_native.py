@@ -139,6 +139,7 @@ _SIGNATURES = {
     "uavac_gather_counts": (C.c_int, [_P, _P, C.c_int64, _P]),
     "uavac_gather_rows_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, C.c_int, _P]),
     "uavac_gather_plan_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, _P, _P, _P]),
+    "uavac_gather_plan_part_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "uavac_comm_versions": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "uavac_comm_finish": (C.c_int, [_P, _P]),
     "uavac_comm_loopback_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
@@ -160,7 +161,7 @@ def lib() -> C.CDLL:
                                        "to let the first import do it); there is no CPU fallback")
             import subprocess
             try:
-                subprocess.run(["make", "-C", pkg, "-j4"], check=True, capture_output=True)
+                subprocess.run(["make", "-C", pkg, "-j4", "lib"], check=True, capture_output=True)
             except Exception as exc:
                 raise UavacError(EHIP, f"{LIB_PATH} not built and `make -C {pkg}` failed: {exc}") from exc
             # a library built here is CHECKED here, like one built by __graft_entry__.build(): register budgets and the

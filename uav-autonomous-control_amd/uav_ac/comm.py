@@ -92,26 +92,52 @@ class RcclComm:
         e._bind_stream()                                      # back on the caller's stream
         return (stream, out, counts, rows)
 
-    def gather_plan(self, plan: Plan, dst: int = 0, traj=None):
+    def gather_plan(self, plan: Plan, dst: int = 0, traj=None, parts=None):
         """The final gather as a gather of the PLAN: every rank sends the coefficients, durations and per-spline row
-        counts of its missions (204 B per spline; ~10 KB of rows per spline stay where they are), and `dst` re-samples
+        counts of its missions (204 B per spline; ~10 KB of rows per spline stay where they are -- or were never sampled: a
+        rows-free plan, `Engine.plan(rows=False)`, travels just the same), and `dst` re-samples
         them with the very kernel the peers ran -> (Plan of all missions on dst | None, row counts per rank).  A ragged
         batch (`RaggedBatch`, or the `RaggedPlan` of `plan_collision_free`) travels the same way, with the number of splines
         of every mission as one more column, and comes back as a RaggedBatch.
         `gathered.traj` equals what `gather_rows(plan.traj)` delivers, bit for bit.  Synchronous."""
-        return self.gather_finish(self.gather_plan_begin(plan, dst, traj=traj))
+        return self.gather_finish(self.gather_plan_begin(plan, dst, traj=traj, parts=parts))
 
-    def gather_plan_begin(self, plan: Plan, dst: int = 0, stream=None, traj=None):
+    def plan_counts(self, plan):
+        """(segments per rank, rows per rank) of a plan gather: two tiny synchronous all-gathers.  `gather_plan_begin(...,
+        known_counts=...)` takes them from a previous call for the same job instead of asking again."""
+        ragged = not hasattr(plan, "m")
+        n_seg = int(plan.seg_offsets_host[-1]) if ragged else plan.B * int(plan.m)
+        self.engine._bind_stream()
+        return self.counts(n_seg), self.counts(plan.total_rows)
+
+    def _transfer_stream(self):
+        if getattr(self, "_xfer", None) is None:
+            self._xfer = self.engine._torch.cuda.Stream(device=self.engine.device)
+        return self._xfer
+
+    def gather_plan_begin(self, plan: Plan, dst: int = 0, stream=None, traj=None, parts=None, known_counts=None):
         """Enqueue `gather_plan` and return at once (`stream`, ticket, and what may run meanwhile: as for `gather_rows_begin`;
         the root's re-sampling is enqueued on that stream too, behind the receives).  `traj`: a preallocated row buffer for
         the root.  A ragged batch makes the root wait inside this call for the splines-per-mission column (it sizes the
-        segment table on the host); a uniform batch returns at once on every rank."""
+        segment table on the host); a uniform batch returns at once on every rank.
+        `parts` (uniform batches): None = one transfer, then one re-sampling.  True or a tuple of cumulative shares
+        (`sharding.PIPELINE_SHARES`) = PIPELINED: durations and row counts of the whole blocks travel first (12 B per spline: the
+        root can lay out every mission's rows), then the coefficients in parts (`uavac_gather_plan_part_dev`) on a transfer
+        stream of their own; the root samples part p of every rank's block (`Engine.sample_range`) as soon as it has arrived,
+        while part p + 1 is on its links.  The rows are the same bits in the same places; the root's critical path loses the
+        transfer time of all but the first part.
+        `known_counts` = `plan_counts(plan)` of an earlier gather of the same job: skips the two synchronous all-gathers."""
         e, torch = self.engine, self.engine._torch
         if getattr(plan, "coeffs", None) is None or not plan.coeffs.is_cuda:
             raise ValueError("gather_plan takes a device-resident Plan, RaggedBatch or RaggedPlan with its batch")
         ragged = not hasattr(plan, "m")
         if ragged and getattr(plan, "seg_offsets", None) is None:
             raise ValueError("this plan has neither one segment count for the batch nor seg_offsets")
+        if parts is not None and parts is not False:
+            if ragged:
+                raise ValueError("the pipelined gather cuts blocks at mission boundaries every rank can compute: uniform batches only")
+            from .sharding import PIPELINE_SHARES
+            return self._gather_plan_pipelined(plan, dst, stream, traj, PIPELINE_SHARES if parts is True else tuple(parts), known_counts)
         m = 0 if ragged else int(plan.m)
         n_seg = int(plan.seg_offsets_host[-1]) if ragged else plan.B * m
         here = torch.cuda.current_stream(e.device)
@@ -119,8 +145,7 @@ class RcclComm:
         if stream is not here:
             stream.wait_stream(here)
         with torch.cuda.stream(stream):
-            seg_counts = self.counts(n_seg)                  # tiny synchronous all-gathers on that stream
-            row_counts = self.counts(plan.total_rows)
+            seg_counts, row_counts = known_counts if known_counts is not None else self.plan_counts(plan)
             kw = dict(device=e.device)
             per_mission = b_counts = None
             if ragged:
@@ -153,6 +178,64 @@ class RcclComm:
             keep = (plan, per_mission)
         e._bind_stream()                                      # back on the caller's stream
         return (stream, gathered, row_counts, keep)
+
+    def _gather_plan_pipelined(self, plan, dst, stream, traj, shares, known_counts):
+        e, torch = self.engine, self.engine._torch
+        from .sharding import part_bounds
+        m = int(plan.m)
+        here = torch.cuda.current_stream(e.device)
+        stream = here if stream is None else stream
+        xfer = self._transfer_stream()                        # every RCCL operation of this gather is issued on it
+        xfer.wait_stream(here)
+        if stream is not here:
+            stream.wait_stream(here)
+        root = self.rank == dst
+        kw = dict(device=e.device)
+        times = getattr(plan, "times", None)
+        arr = lambda v: (C.c_int64 * self.world)(*[int(x) for x in v])      # noqa: E731
+        events, co = [], None
+        with torch.cuda.stream(xfer):
+            seg_counts, row_counts = known_counts if known_counts is not None else self.plan_counts(plan)
+            if any(c % m for c in seg_counts):
+                raise ValueError(f"every rank must plan with the same segment count (m = {m} here)")
+            missions = [c // m for c in seg_counts]
+            bounds = [part_bounds(b, shares) for b in missions]             # the same arithmetic on every rank
+            S = sum(seg_counts)
+            tm = sr = None
+            if root:
+                co = torch.empty((S, 8, 3), dtype=torch.float64, **kw)
+                tm = torch.empty((S,), dtype=torch.float64, **kw) if times is not None else None
+                sr = torch.empty((S,), dtype=torch.int32, **kw)
+            e._bind_stream()
+            # durations + rows per spline of the WHOLE blocks first: the root lays out every mission's rows from them
+            e.ctx.call("uavac_gather_plan_part_dev", self._h, None, _ptr(times), _ptr(plan.seg_rows), arr(seg_counts),
+                       arr([0] * self.world), arr(seg_counts), int(dst), None, _ptr(tm), _ptr(sr))
+            for p in range(len(shares)):
+                first = [bounds[r][p] * m for r in range(self.world)]
+                count = [(bounds[r][p + 1] - bounds[r][p]) * m for r in range(self.world)]
+                e.ctx.call("uavac_gather_plan_part_dev", self._h, _ptr(plan.coeffs), None, None, arr(seg_counts), arr(first), arr(count),
+                           int(dst), _ptr(co), None, None)
+                if root:
+                    ev = torch.cuda.Event()
+                    ev.record(xfer)
+                    events.append(ev)
+        gathered = None
+        if root:
+            with torch.cuda.stream(stream):
+                stream.wait_event(events[0])
+                gathered = e.plan_from_parts(co, tm, sr, m, plan.velocity, plan.dt, total_rows=sum(row_counts), traj=traj, sample=False)
+                base = np.concatenate([[0], np.cumsum(missions)])
+                for p in range(len(shares)):
+                    if p:
+                        stream.wait_event(events[p])
+                    for r in range(self.world):
+                        e.sample_range(gathered, base[r] + bounds[r][p], base[r] + bounds[r][p + 1])
+                for t in (co, tm, sr):                        # allocated under the transfer stream, read by the sampler on `stream`
+                    if t is not None:
+                        t.record_stream(stream)
+        stream.wait_stream(xfer)                              # whoever waits for `stream` (gather_finish) has waited for the transfers
+        e._bind_stream()                                      # back on the caller's stream
+        return (stream, gathered, row_counts, (plan, None))
 
     def gather_finish(self, ticket):
         """Wait for a gather started with `gather_rows_begin` / `gather_plan_begin` -> (result on dst | None, counts)."""

@@ -15,16 +15,18 @@ def _torch():
     return torch
 
 
-def gather_plan(plan, dst: int = 0, group=None, comm: "RcclComm" = None, engine: "Engine" = None):
+def gather_plan(plan, dst: int = 0, group=None, comm: "RcclComm" = None, engine: "Engine" = None, parts=None):
     """`RcclComm.gather_plan` with the host rehearsal path beside it (like `gather_rows`).
 
     A device-resident Plan + `comm`: RCCL behind the C ABI.  Otherwise the plan's parts travel as HOST tensors through
     `torch.distributed` point-to-point messages (gloo) in the same layout -- the rehearsal path of the multi-process CPU
     tests and of `UAVAC_BENCH_REHEARSAL`; on dst the result is a Plan re-sampled on `engine`'s GPU when one is given, else
-    the gathered parts `{"coeffs", "times", "seg_rows", "m"}` as host tensors.  Returns (result | None, row counts)."""
+    the gathered parts `{"coeffs", "times", "seg_rows", "m"}` as host tensors.  Returns (result | None, row counts).
+    `parts` (True or cumulative shares, with `engine`): re-sample in the ORDER of the pipelined RCCL gather -- part p of every
+    rank's block, part after part (`Engine.sample_range`) -- nothing is pipelined over gloo, the rows must not care."""
     torch = _torch()
     if comm is not None and getattr(plan.coeffs, "is_cuda", False):
-        return comm.gather_plan(plan, dst)
+        return comm.gather_plan(plan, dst, parts=parts)
     import torch.distributed as dist
     if not hasattr(plan, "m"):
         raise ValueError("the host (gloo) path of gather_plan takes a Plan with one segment count for the batch; a ragged "
@@ -42,6 +44,20 @@ def gather_plan(plan, dst: int = 0, group=None, comm: "RcclComm" = None, engine:
     counts = [int(c.item()) for c in counts]
     if dist.get_rank(group) != dst:
         return None, counts
+    if engine is not None and parts:
+        from .sharding import PIPELINE_SHARES, part_bounds
+        shares = PIPELINE_SHARES if parts is True else tuple(parts)
+        b_counts = [torch.zeros_like(n) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(b_counts, torch.tensor([int(plan.B)], dtype=torch.int64), group=group)
+        missions = [int(c.item()) for c in b_counts]
+        got = engine.plan_from_parts(co.reshape(-1, 8 * m, 3), None if tm is None else tm.reshape(-1, m), sr.reshape(-1, m), m,
+                                     plan.velocity, plan.dt, total_rows=sum(counts), sample=False)
+        base = np.concatenate([[0], np.cumsum(missions)])
+        bounds = [part_bounds(b, shares) for b in missions]
+        for p in range(len(shares)):
+            for r in range(len(missions)):
+                engine.sample_range(got, base[r] + bounds[r][p], base[r] + bounds[r][p + 1])
+        return got, counts
     if engine is not None:
         return engine.plan_from_parts(co.reshape(-1, 8 * m, 3), None if tm is None else tm.reshape(-1, m), sr.reshape(-1, m), m,
                                       plan.velocity, plan.dt, total_rows=sum(counts)), counts

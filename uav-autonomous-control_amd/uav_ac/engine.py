@@ -360,13 +360,31 @@ class Engine:
                       plan.B, plan.max_m if ragged else plan.m, float(plan.dt), _ptr(out))
         return out
 
+    def sample_range(self, plan: Plan, b0: int, b1: int):
+        """The rows (and first headings) of missions [b0, b1) of a uniform plan, written where `sample(plan)` writes them: the
+        row offsets are absolute, so a sub-range is the same kernel on offset pointers.  Any cover of [0, B) by ranges, in any
+        order, leaves the rows of one `sample(plan)` bit for bit -- what lets the root of a pipelined plan gather sample a part
+        of every peer's block while the next part arrives.  No allocation, no sync."""
+        b0, b1 = int(b0), int(b1)
+        if not (0 <= b0 <= b1 <= plan.B):
+            raise ValueError("need 0 <= b0 <= b1 <= plan.B")
+        if plan.traj is None:
+            raise ValueError("a rows-free plan has no row buffer: Engine.sample_rows(plan) allocates one and samples")
+        if b1 == b0:
+            return
+        self._bind_stream()
+        fy = getattr(plan, "first_yaw", None)
+        self.ctx.call("uavac_minsnap_sample_derivs_dev", _ptr(plan.coeffs[b0:b1]), _ptr(plan.seg_rows[b0:b1]), _ptr(plan.row_offsets[b0:]),
+                      b1 - b0, plan.m, plan.dt, _ptr(plan.traj), _ptr(plan.yaw), _ptr(None if fy is None else fy[b0:b1]), None, None)
+
     def plan_from_parts(self, coeffs, times, seg_rows, m: int, velocity: float, dt: float, total_rows: int = None,
-                        traj=None) -> Plan:
+                        traj=None, sample: bool = True) -> Plan:
         """A Plan from its solved parts -- coefficients (B, 8m, 3), durations (B, m) or None, rows per spline (B, m) -- e.g.
         the peers' plans after `RcclComm.gather_plan`: row offsets from the row counts (`uavac_minsnap_row_offsets_dev`),
         then the sampler writes the rows (and the first headings).  The rows are a deterministic function of coefficients,
         row counts and dt: bit-identical to the rows of the plan the parts came from.  `total_rows` (when the caller knows
-        it) avoids the one host synchronisation that sizes the row buffer; `traj`: a preallocated (>= total, 11) buffer."""
+        it) avoids the one host synchronisation that sizes the row buffer; `traj`: a preallocated (>= total, 11) buffer.
+        `sample=False`: lay the rows out (offsets, buffers) but leave the sampling to the caller's `sample_range` calls."""
         torch = self._torch
         co = self._dev(coeffs, torch.float64).reshape(-1, 8 * int(m), 3)
         sr = self._dev(seg_rows, torch.int32).reshape(-1, int(m))
@@ -386,7 +404,8 @@ class Engine:
         first_yaw = torch.empty((B,), dtype=torch.float64, **kw)
         status = torch.zeros((B,), dtype=torch.int32, **kw)
         plan = Plan(B, int(m), float(velocity), float(dt), None, tm, sr, row_offsets, co, status, traj[:total], total, None, first_yaw)
-        self.sample(plan)
+        if sample:
+            self.sample(plan)
         return plan
 
     def ragged_from_parts(self, coeffs, times, seg_rows, seg_counts, velocity: float, dt: float, total_rows: int = None,

@@ -134,6 +134,23 @@ def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_
     return 0.5 * (lo + hi)
 
 
+# How a pipelined plan gather cuts every rank's block (`RcclComm.gather_plan_begin(parts=...)`): cumulative shares of the
+# missions.  The first part is small so that the root starts sampling early; every part takes the sampler longer than the next
+# one takes to arrive (the sampler consumes a plan at ~2 % of the rate it writes rows: ~15 GB/s per link at eight ranks), and the
+# late parts are large launches.
+PIPELINE_SHARES = (1.0 / 16, 1.0 / 4, 1.0 / 2, 1.0)
+
+
+def part_bounds(n_missions: int, shares=PIPELINE_SHARES):
+    """Mission-index boundaries [0, b1, ..., n] of the parts of a block of n missions, from cumulative `shares` (increasing, the
+    last one 1).  Pure arithmetic: every rank computes every rank's boundaries from the mission counts alone."""
+    shares = tuple(float(s) for s in shares)
+    if not shares or shares[-1] != 1.0 or any(b <= a for a, b in zip((0.0,) + shares, shares)):
+        raise ValueError("shares: increasing cumulative fractions ending in 1")
+    n = int(n_missions)
+    return [0] + [min(n, int(n * s)) for s in shares[:-1]] + [n]
+
+
 def gather_layout(counts, dst: int):
     """Where every rank's block lands in the root's buffer: row offsets (world + 1,) and the peers that send.
     Shared by the RCCL path (whose C side derives the same offsets from the same counts) and the host rehearsal."""
