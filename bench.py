@@ -33,6 +33,7 @@ their source, rows re-sampled from the gathered plan that differ from the gather
 that died: exit status 3, always -- rc 0 means the trajectories on rank 0 were right.
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -441,24 +442,27 @@ def main():
                          "kernel_vgprs": eng.ctx.last_rollout_vgprs(),
                          "rollout_source_sha": rollout_source_sha()},
             "build": nat_build_info(),
-            # (BASELINE's second metric is quoted on the MEDIAN planning chain of the timed steps: one step in twenty that follows a
-            # host-side hiccup can take 4x as long and would move a mean by 14 %; the mean is beside it and is what `value` paid)
-            "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / (float(np.median(plan_ms)) * 1e-3), "unit": "segments/s",
-                        "ms_solve_plus_sample": float(np.median(plan_ms)), "ms_mean": plan_avg_s * 1e3,
+            # BASELINE's second metric.  `value`, `ms_solve_plus_sample` and `roofline.frac` are on the MEAN of the timed steps'
+            # planning chains -- what rounds 1-4 reported and what `value` above paid; round 5 had silently moved these keys to the
+            # median (round-5 advice).  The median -- one step in twenty that follows a host-side hiccup can take 4x as long and move a
+            # mean by 14 % -- is beside them under its own names: `value_median`, `ms_median`, `frac_median`, `roofline.frac_median`.
+            "minsnap": {"metric": "min-snap segments solved/sec", "value": B * m / plan_avg_s, "unit": "segments/s",
+                        "statistic": "value / ms_solve_plus_sample / roofline.frac: MEAN over the timed steps (as in rounds 1-4); *_median: their median",
+                        "ms_solve_plus_sample": plan_avg_s * 1e3, "ms_mean": plan_avg_s * 1e3,
+                        "value_median": B * m / plan_med_s,
                         "ms_per_timed_step": [round(x, 4) for x in plan_ms],
-                        # the planning chain of every timed step (HIP events round the one C call): the mean above prices `value`;
-                        # median and spread say what the instrument resolves
+                        # the planning chain of every timed step (HIP events round the one C call)
                         "ms_median": float(np.median(plan_ms)), "ms_min": float(np.min(plan_ms)), "ms_max": float(np.max(plan_ms)),
-                        "frac_median": plan.algorithmic_bytes / (float(np.median(plan_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_median": plan.algorithmic_bytes / plan_med_s / 1e9 / HBM_PEAK_GBS,
                         "row_buffer": "first allocation (Engine.plan's default: no placement search)",
                         "solve": "two-ended block-Thomas, two lanes per mission (csrc/minsnap_solve_tw.hip; option solve_order = 1, the default)",
-                        "frac_first_allocation": plan.algorithmic_bytes / plan_med_s / 1e9 / HBM_PEAK_GBS,
-                        "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_med_s / 1e9,
+                        "roofline": {"bound": "hbm", "achieved": plan.algorithmic_bytes / plan_avg_s / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": plan.algorithmic_bytes / plan_med_s / 1e9 / HBM_PEAK_GBS,
+                                     "frac": plan.algorithmic_bytes / plan_avg_s / 1e9 / HBM_PEAK_GBS,
+                                     "frac_median": plan.algorithmic_bytes / plan_med_s / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes": plan.algorithmic_bytes,
                                      "traffic": plan_traffic,
-                                     "frac_counter_bytes": (plan_traffic / plan_med_s / 1e9 / HBM_PEAK_GBS)
+                                     "frac_counter_bytes": (plan_traffic / plan_avg_s / 1e9 / HBM_PEAK_GBS)
                                      if plan_traffic is not None else None,
                                      "traffic_source": ("profiles/hbm_traffic.json: K1 + K2 counter bytes per planning chain "
                                                         "(same sampler / solver sources)") if plan_traffic is not None else None},
@@ -476,6 +480,14 @@ def main():
                                        "achieved": rate, "peak": FP64_WAVE_INSTR_PEAK, "unit": "VALU wave-instr/s",
                                        "frac": rate / FP64_WAVE_INSTR_PEAK,
                                        "source": "profiles/hbm_traffic.json (tools/pmc_traffic.py, SQ_INSTS_VALU)"}
+
+    # The headline exists: say so on stderr at once, before the diagnostics and before any config-4 collective -- a crash inside
+    # RCCL on first contact with real peers cannot lose it (stdout still carries exactly ONE line, at the end).
+    if rank == 0:
+        print(json.dumps({"early": True, "note": "headline measured; diagnostics and the config-4 leg follow; the full line goes to stdout",
+                          **{k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype")},
+                          "roofline_frac": out["roofline"]["frac"], "minsnap_segments_per_s": out["minsnap"]["value"]}),
+              file=sys.stderr, flush=True)
 
     # ---- untimed diagnostics: per-launch durations of one more step, and the rollout on a flyable distribution -------
     if not args.no_extras:
@@ -565,16 +577,22 @@ def main():
         del slow, fl2
 
     # ---- BASELINE configs[3] on the same N GPUs: 262 144 UAVs in total, m = 8, 5 000 ticks, gather to rank 0 ----------
+    # Two forms of the job, side by side in the line:
+    #   LITERAL  every rank plans WITH rows and flies, then the rows travel to rank 0 (uavac_gather_rows_dev: 18-20 GB into the
+    #            root's links) -- or, round 3, the plan travels and rank 0 re-samples (the peers' rows are then sampled twice);
+    #   ROUND 6  every rank plans ROWS-FREE (times, row counts, solve, first headings: not one row), flies plan-fed and ships its
+    #            plan in parts; rank 0 samples everybody's rows ONCE, part by part as they arrive, beside its own flight
+    #            (`config4.end_to_end`).  Same rows on rank 0, bit for bit -- verified against the literal row gather in this run.
     gather_err = None
     comm = None
     if not args.no_config4:
         del plan, fleet, log
         torch.cuda.empty_cache()
-        from uav_ac.fleet import balanced_root_share, candidate_shard_sizes, measure_tick_table, shard_bounds, shard_sizes
-        # contiguous blocks; rank 0 -- the root of the final gather, which takes everybody's rows into its HBM while it flies --
+        from uav_ac.sharding import balanced_root_share, candidate_shard_sizes, measure_tick_table, shard_bounds, shard_sizes
+        # contiguous blocks; rank 0 -- the root of the final gather, which writes everybody's rows into its HBM while it flies --
         # gets a smaller block so that it finishes with its peers.  How much smaller follows from what a shard of n missions costs
-        # on THESE GPUs: every rank measures three candidate sizes (a few tens of ms), the slowest rank's numbers count, and the
-        # table goes into the line (`config4.tick_table`).  UAVAC_BENCH_TICK_TABLE='[[n, us_per_tick, plan_ms_per_1000], ...]'
+        # on THESE GPUs: every rank measures four candidate sizes (a few tens of ms), the slowest rank's numbers count, and the
+        # table goes into the line (`config4.tick_table`).  UAVAC_BENCH_TICK_TABLE='[[n, us_per_tick, plan_ms_per_1000, rows_free_plan_ms_per_1000], ...]'
         # injects a table instead (tests).
         root_share, tick_table = None, None
         if world > 1 and not args.equal_shards:
@@ -584,16 +602,18 @@ def main():
             else:
                 sizes_c = candidate_shard_sizes(C4_TOTAL, world)
                 mine = measure_tick_table(eng, C4_SEGMENTS, sizes_c, VELOCITY, DT)
-                t = torch.tensor([[us, pm] for _, us, pm in mine], dtype=torch.float64, device=cdev)
+                t = torch.tensor([list(row[1:]) for row in mine], dtype=torch.float64, device=cdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tick_table = [(n, float(a_), float(b_)) for (n, _, _), (a_, b_) in zip(mine, t.cpu().tolist())]
+                tick_table = [(row[0],) + tuple(float(v) for v in cols) for row, cols in zip(mine, t.cpu().tolist())]
             root_share = balanced_root_share(C4_TOTAL, world, C4_TICKS, C4_SEGMENTS, tick_table=tick_table)
         sizes4 = shard_sizes(C4_TOTAL, world, root_share, 0)
         lo4, hi4 = shard_bounds(C4_TOTAL, rank, world, root_share, 0)
         B4 = hi4 - lo4
         wps4 = missions(C4_TOTAL, C4_SEGMENTS, lo4, hi4)
-        plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)
+        plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)              # the literal form: this rank's rows are sampled here
+        plan4f = eng.plan(wps4, VELOCITY, DT, rows=False)                       # round 6: no rows here; rank 0 samples them all
         fleet4 = eng.fleet(plan4)
+        fleet4f = eng.fleet(plan4f)                                             # plan-fed: all a rows-free plan can be
         pitch4 = -(-B4 // 16) * 16                                                               # rows on 128-byte lines for any B4
         # The 5 000 ticks in as few launches as a 40 GB log allows: ONE at 8 ranks (17-19 GB), two at 2 ranks, five on one GPU.  A
         # launch boundary costs 50-80 us below a full chip (every workgroup waits for the slowest; prologue; aligner): 32 768 UAVs fly
@@ -601,14 +621,18 @@ def main():
         chunk4 = next(c for c in (5000, 2500, 1000) if c == 1000 or c * 13 * pitch4 * 8 <= 40e9)
         log4 = torch.empty((chunk4, 13, pitch4), dtype=torch.float64, device=dev)
 
-        def fly4():
-            fleet4.reset()
+        def fly4(fl=fleet4):
+            fl.reset()
             for _ in range(C4_TICKS // chunk4):
-                fleet4.rollout(chunk4, state_log=log4, log_pitch=pitch4)
+                fl.rollout(chunk4, state_log=log4, log_pitch=pitch4)
 
         def step4():
             eng.replan(plan4)
             fly4()
+
+        def step4f():
+            eng.replan(plan4f)
+            fly4(fleet4f)
 
         def timed(fn, reps):
             """max over ranks of the mean wall time of `fn`, bracketed by barriers"""
@@ -626,27 +650,42 @@ def main():
 
         step4()
         c4_compute = timed(step4, 3)
+        kernel4 = eng.ctx.last_rollout_kernel()
         c4_fly = timed(fly4, 3)                              # the 5 000 ticks alone (planning is 12 % of this job)
+        step4f()
+        c4_compute_free = timed(step4f, 3)
+        kernel4f = eng.ctx.last_rollout_kernel()
         # what re-sampling this rank's rows from its plan costs (at N = 1: all 262 144 missions = what the root of the plan
-        # gather pays at any N, on top of its own share of the flight)
-        a, b = ev(), ev()
+        # gather pays at any N, on top of its own share of the flight), and the two planning chains on their own
+        a, b, c, d = ev(), ev(), ev(), ev()
         eng.sample(plan4)
+        eng.replan(plan4f)
         a.record()
         for _ in range(3):
             eng.sample(plan4)
         b.record()
+        for _ in range(3):
+            eng.replan(plan4)
+        c.record()
+        for _ in range(3):
+            eng.replan(plan4f)
+        d.record()
         torch.cuda.synchronize()
         c4 = {"workload": "BASELINE.json configs[3]: 262144 UAVs in total (strong scaling), 8-segment missions, plan + "
                           "5000 fused ticks (state logged every tick; as few launches as a 40 GB log per rank allows: `ticks_per_launch`), "
                           "trajectories gathered to rank 0",
               "batch_total": C4_TOTAL, "batch_per_gpu": B4, "shard_sizes": sizes4, "root_share": root_share,
-              "tick_table": ([[int(n), round(us, 4), round(pm, 5)] for n, us, pm in tick_table] if tick_table else None),
-              "tick_table_columns": "missions on the GPU, us per logged tick, ms of planning per 1000 missions (max over ranks)",
+              "tick_table": ([[int(row[0])] + [round(v, 5) for v in row[1:]] for row in tick_table] if tick_table else None),
+              "tick_table_columns": "missions on the GPU, us per logged tick, ms of planning per 1000 missions with rows, the same rows-free (max over ranks)",
               "log_pitch": pitch4, "ticks_per_launch": chunk4,
               "segments": C4_SEGMENTS, "ticks": C4_TICKS,
               "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
-              "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": eng.ctx.last_rollout_kernel(),
+              "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": kernel4,
               "rollout_ms": c4_fly * 1e3, "steps_per_s_rollout_only": C4_TOTAL * C4_TICKS / c4_fly,
+              # round 6: the same job with the rows-free planning chain on every rank (what `end_to_end` runs)
+              "compute_rows_free_ms": c4_compute_free * 1e3, "steps_per_s_compute_only_rows_free": C4_TOTAL * C4_TICKS / c4_compute_free,
+              "rollout_kernel_rows_free": kernel4f,
+              "plan_chain_rank0_ms": {"with_rows": b.elapsed_time(c) / 3, "rows_free": c.elapsed_time(d) / 3},
               "resample_rank0_rows_ms": a.elapsed_time(b) / 3,
               "plan_bytes_rank0": int(plan4.B * C4_SEGMENTS * 204), "row_bytes_rank0": int(plan4.total_rows * 88)}
         if rank == 0:
@@ -671,29 +710,34 @@ def main():
                 return int(t.item()) == 0
 
             try:
-                from uav_ac.comm_host import gather_plan, gather_rows      # (host tensors over gloo: the rehearsal transport)
                 SLICE = 200000                             # rehearsal: rows per rank that cross gloo (control flow only)
                 if rehearsal:
+                    from uav_ac.comm_host import gather_plan, gather_rows      # host tensors over gloo: the rehearsal transport
+
                     def rows_gather():
                         g, c = gather_rows(plan4.traj[:SLICE].cpu(), dst=0)
                         return (g.to(dev) if g is not None else None), c
 
-                    def plan_gather():
-                        return gather_plan(plan4, dst=0, engine=eng)
+                    def plan_gather(p=plan4, parts=None):
+                        return gather_plan(p, dst=0, engine=eng, parts=parts)
                 else:
                     comm = RcclComm(eng)                   # ncclCommInitRank behind the C ABI; id travels over the process group
                     comm.gather_rows(plan4.traj[:1024], dst=0)      # connection set-up is not part of any timed gather
                     rccl_ranks, rccl_rank = comm.shape()            # what the communicator itself says (ncclCommCount / UserRank)
                     if rank == 0:
                         c4["rccl_ranks"] = rccl_ranks
+                        built, runtime = ctypes.c_int(), ctypes.c_int()
+                        from uav_ac import _native as nat
+                        nat.lib().uavac_comm_versions(ctypes.byref(built), ctypes.byref(runtime))
+                        c4["rccl_versions"] = {"built_with": int(built.value), "runtime": int(runtime.value)}
                     if (rccl_ranks, rccl_rank) != (world, rank):
                         raise RuntimeError(f"the RCCL communicator has {rccl_ranks} ranks / this is its rank {rccl_rank}; the process group says {world} / {rank}")
 
                     def rows_gather():
                         return comm.gather_rows(plan4.traj, dst=0)
 
-                    def plan_gather():
-                        return comm.gather_plan(plan4, dst=0)
+                    def plan_gather(p=plan4, parts=None):
+                        return comm.gather_plan(p, dst=0, parts=parts)
 
                 # which physical GPU every rank flew on, gathered over the process group: N ranks must name N devices
                 idents = [None] * world
@@ -733,9 +777,9 @@ def main():
                                "gather_verified": ok})
 
                 # ---- the gather of the PLAN (coefficients, durations, rows per spline; the root re-samples): once untimed,
-                # verified against the rows the row gather delivered, then timed
-                gp, pcounts = plan_gather()
-                if rank == 0:
+                # verified against the rows the row gather delivered, then timed -- in one shot from the full plans (round 3) and
+                # PIPELINED from the rows-free plans (round 6: parts on a transfer stream, each sampled when it has arrived)
+                def same_as_gathered(gp, pcounts):
                     total_rows = sum(pcounts)
                     if rehearsal:                          # only a slice of every peer's rows crossed gloo
                         offs_full = np.concatenate([[0], np.cumsum(pcounts)])
@@ -745,47 +789,80 @@ def main():
                             same = same and bool((gp.traj[offs_full[r]:offs_full[r] + n] == gathered[offs[r]:offs[r] + n]).all())
                     else:
                         same = pcounts == counts and gp.traj.shape == gathered.shape and bool((gp.traj == gathered).all())
-                    same = same and bool((gp.coeffs[:plan4.B] == plan4.coeffs).all()) and \
-                        bool((gp.row_offsets[:plan4.B + 1] == plan4.row_offsets).all())
+                    return same and bool((gp.coeffs[:plan4.B] == plan4.coeffs).all()) and \
+                        bool((gp.row_offsets[:plan4.B + 1] == plan4.row_offsets).all()) and \
+                        bool((gp.first_yaw[:plan4.B] == plan4.first_yaw).all())
+
+                gp, pcounts = plan_gather()
+                if rank == 0:
+                    same = same_as_gathered(gp, pcounts)
                     if not same:
                         gather_err = gather_err or "rows re-sampled from the gathered plan differ from the gathered rows"
                     c4["plan_gather_verified"] = bool(same)
                     c4["plan_gather_bytes_into_root"] = int((C4_TOTAL - B4) * C4_SEGMENTS * 204)        # coefficients 192 + duration 8 + rows 4
-                del gathered, gp
-                plan_s = timed(lambda: holder.append(plan_gather()) or holder.clear(), 2)
+                del gp
+                gp, pcounts = plan_gather(plan4f, True)
                 if rank == 0:
-                    c4.update({"plan_gather_ms": plan_s * 1e3,
+                    same = same_as_gathered(gp, pcounts)
+                    if not same:
+                        gather_err = gather_err or "rows sampled from the pipelined gather of the rows-free plans differ from the gathered rows"
+                    c4["pipelined_plan_gather_verified"] = bool(same)
+                del gp
+                plan_s = timed(lambda: holder.append(plan_gather()) or holder.clear(), 2)
+                pipe_s = timed(lambda: holder.append(plan_gather(plan4f, True)) or holder.clear(), 2)
+                if rank == 0:
+                    c4.update({"plan_gather_ms": plan_s * 1e3, "pipelined_plan_gather_ms": pipe_s * 1e3,
                                "steps_per_s_with_plan_gather": C4_TOTAL * C4_TICKS / (c4_compute + plan_s)})
 
                 # The same job with the gather BESIDE the rollout instead of after it: the trajectories are final when
-                # planning ends, so their transfer (rows), or the transfer of the plan and the root's re-sampling, starts
+                # planning ends, so their transfer (rows), or the transfer of the plan and the root's sampling, starts
                 # there on a second stream while the vehicles fly.  A problem here is reported (`overlap_error`) but does
                 # not fail the run -- the verified serial gathers above are the ones that count.
                 # (whether to go on is decided by all ranks together: only rank 0 knows what its verifications found)
                 if everybody_fine(gather_err) and not rehearsal:
                     side = torch.cuda.Stream(device=dev)
+                    known = comm.plan_counts(plan4f)                  # the all-gathers of the counts: once, outside the timed job
+                    traj_all = torch.empty((sum(counts), 11), dtype=torch.float64, device=dev) if rank == 0 else None
 
-                    def overlapped(begin):
+                    def overlapped(p, fl, begin, root_flies_first=False):
                         def run():
-                            eng.replan(plan4)
-                            ticket = begin(plan4, side)
-                            fly4()
+                            eng.replan(p)
+                            # The root's rollout must be RESIDENT before its sampler starts: the sampler's grid never leaves 256 free
+                            # registers on a SIMD while it has workgroups left, and a rollout workgroup that arrives behind it waits
+                            # for its last wave (profiles/r06_config4_root_overlap_order.jsonl: 8.1 ms against 5.1).  The peers
+                            # enqueue their sends first: the root waits for them.
+                            if root_flies_first and rank == 0:
+                                fly4(fl)
+                                ticket = begin(p, side)
+                            else:
+                                ticket = begin(p, side)
+                                fly4(fl)
                             got, cnt = comm.gather_finish(ticket)
                             torch.cuda.synchronize()
                             return got, cnt
                         return run
 
-                    variants = (("rows", overlapped(lambda p, st: comm.gather_rows_begin(p.traj, dst=0, stream=st)),
-                                 "overlapped_ms", "steps_per_s_gather_overlapped", "overlapped_verified"),
-                                ("plan", overlapped(lambda p, st: comm.gather_plan_begin(p, dst=0, stream=st)),
-                                 "plan_overlapped_ms", "steps_per_s_plan_gather_overlapped", "plan_overlapped_verified"))
-                    for kind, run, k_ms, k_rate, k_ok in variants:
+                    variants = (("rows", overlapped(plan4, fleet4, lambda p, st: comm.gather_rows_begin(p.traj, dst=0, stream=st)),
+                                 "overlapped_ms", "steps_per_s_gather_overlapped", "overlapped_verified",
+                                 "plan with rows + 5000 ticks, the rows gathered to rank 0 beside the flight"),
+                                ("plan", overlapped(plan4, fleet4, lambda p, st: comm.gather_plan_begin(p, dst=0, stream=st)),
+                                 "plan_overlapped_ms", "steps_per_s_plan_gather_overlapped", "plan_overlapped_verified",
+                                 "plan with rows on every rank + 5000 ticks, the plan gathered in one shot and re-sampled on rank 0 beside the "
+                                 "flight (round 5: the peers' rows are sampled twice)"),
+                                ("rows_free", overlapped(plan4f, fleet4f, lambda p, st: comm.gather_plan_begin(
+                                    p, dst=0, stream=st, traj=traj_all, parts=True, known_counts=known), root_flies_first=True),
+                                 "rows_free_overlapped_ms", "steps_per_s_rows_free_overlapped", "rows_free_overlapped_verified",
+                                 "every rank plans ROWS-FREE (times, row counts, solve, first headings) and flies plan-fed; the plan travels in "
+                                 "parts and rank 0 samples all rows once, part by part, beside its own flight (rank 0 alone sampled)"))
+                    for kind, run, k_ms, k_rate, k_ok, form in variants:
                         over_err, same = None, True
                         try:
                             got, cnt = run()
                             if rank == 0:
                                 rows_ = got if kind == "rows" else got.traj
                                 same = sum(cnt) == rows_.shape[0] and bool((rows_[:cnt[0]] == plan4.traj[:cnt[0]]).all())
+                                if kind == "rows_free":               # ... and every peer's rows, against the literal row gather
+                                    same = same and rows_.shape == gathered.shape and bool((rows_ == gathered).all())
                             del got
                         except Exception as exc:
                             over_err = f"{type(exc).__name__}: {exc}"
@@ -796,13 +873,13 @@ def main():
                                 over_err, over_s = f"{type(exc).__name__}: {exc}", float("nan")
                             if rank == 0 and over_err is None:
                                 c4.update({k_ms: over_s * 1e3, k_ok: bool(same), k_rate: C4_TOTAL * C4_TICKS / over_s})
-                                if kind == "plan" and same:        # THE config-4 job: plan, fly, trajectories resident on rank 0
-                                    c4["end_to_end"] = {"form": "plan + 5000 ticks, the plan gathered and re-sampled on rank 0 beside the flight",
-                                                        "ms": over_s * 1e3, "steps_per_s": C4_TOTAL * C4_TICKS / over_s}
+                                if kind != "rows" and same:           # THE config-4 job: plan, fly, trajectories resident on rank 0
+                                    c4["end_to_end"] = {"form": form, "ms": over_s * 1e3, "steps_per_s": C4_TOTAL * C4_TICKS / over_s}
                         if rank == 0 and over_err is not None:
                             c4["overlap_error"] = f"{kind}: {over_err}"
                         if not everybody_fine(over_err):
                             break
+                del gathered
             except Exception as exc:                      # the timed result above must survive a collective problem
                 gather_err = f"{type(exc).__name__}: {exc}"
             watchdog.cancel()

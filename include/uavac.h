@@ -39,8 +39,9 @@ extern "C" {
 #define UAVAC_ESINGULAR (-4) /* a mission's knot system is singular (e.g. repeated waypoint) */
 #define UAVAC_ENOMEM (-5)
 #define UAVAC_ECOMM (-6)     /* RCCL error (text in uavac_last_error)              */
-#define UAVAC_ETOOLCHAIN (-7)/* uavac_create's self-check: the device math library's atan2 no longer has the bits this build's
-                                sampler reproduces (rebuild against the new toolchain; text on stderr) */
+#define UAVAC_ETOOLCHAIN (-7)/* uavac_create's self-check (first context of a process): the atan2 of the device math library this build
+                                linked no longer has the bits its sampler's heading() reproduces -- heading() (csrc/minsnap_yaw.h) must
+                                be re-derived for that library; rebuilding alone reproduces the failure (text on stderr) */
 
 #define UAVAC_MAX_SEGMENTS 64   /* m, segments per mission                          */
 #define UAVAC_TRAJ_COLS 11      /* x y z vx vy vz ax ay az yaw spline_id: minimum_snap.py:122-123 */
@@ -129,13 +130,17 @@ int uavac_clock_probe_dev(uavac_ctx *ctx, int window_us, int64_t *stamps);
  * many 64-row chunks of the sampler's dense yaw column are written together.  "late_handover": -1
  * (default: chosen per launch), 0, 1 = when the compute wave hands a tick's log values to the store
  * wave.  "lds_pad": extra LDS bytes per rollout workgroup (caps the workgroups a CU takes; 0).
+ * "plan_blocks": 1 (default: off) .. 8 = uavac_minsnap_plan_dev cuts the batch into that many mission blocks and samples block i
+ * on a stream of the ctx's own while block i + 1 is being solved on the caller's (which waits for all of them at the end).
  * "cu_balance": 1 (default) = a logged rollout that needs two or three workgroups on every CU sizes their LDS so
  * that no CU takes more of them than its even share (the dispatcher otherwise gives some CUs three and
  * some one where two each would do), 0 = off.
  * "solve_order" is NOT a tuning knob -- it selects the elimination order of the coefficient solve and with
  * it the rounding: 1 (default) = two-ended, two lanes per mission that meet at the middle knot
  * (csrc/minsnap_solve_tw.hip); 0 = one-ended (csrc/minsnap_solve_bt.hip, rounds 1-4), kept as the
- * cross-check; the two agree to ~5e-14 relative on the coefficients.
+ * cross-check; the two agree to ~5e-14 relative on the coefficients.  -1 (opt-in) = the launcher picks the faster of the two by
+ * (m, B) -- one-ended for uniform batches of m <= 8 from 48 missions per SIMD on -- at the price that a mission's last bits then
+ * depend on the size of the batch it is planned in (the default keeps a shard's coefficients equal to the whole job's).
  * "idle_waves": -1 (default: chosen per launch), 0, 1 = a placeholder wave between the compute and the
  * store wave of every rollout workgroup, which lets two workgroups on a CU occupy all four SIMDs
  * (16 385 .. 32 768 UAVs).  "coeff_dma": -1 (default: chosen per launch), 0, 1, 2 = the plan-fed rollout's mode: 0 the compute

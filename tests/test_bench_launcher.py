@@ -70,7 +70,9 @@ def test_rehearsal_ranks_through_the_self_launcher_plan_gather_equals_row_gather
     if n == 3:
         assert c4["tick_table"] == table
     else:
-        assert [row[0] for row in c4["tick_table"]] == [65536, 131072, 262144] and all(us > 0 and pm > 0 for _, us, pm in c4["tick_table"])
+        # (round 6: four candidate sizes, and the rows-free planning chain as a fourth column)
+        assert [row[0] for row in c4["tick_table"]] == [16384, 65536, 131072, 262144]
+        assert all(len(row) == 4 and min(row[1:]) > 0 for row in c4["tick_table"])
     sizes = shard_sizes(262144, n, balanced_root_share(262144, n, 5000, 8, tick_table=c4["tick_table"]), 0)
     assert all(abs(a - b) <= 2 for a, b in zip(c4["shard_sizes"], sizes))       # (the line's table is rounded to 4 digits)
     sizes = c4["shard_sizes"]
@@ -78,6 +80,8 @@ def test_rehearsal_ranks_through_the_self_launcher_plan_gather_equals_row_gather
     assert c4["batch_per_gpu"] == sizes[0] and sum(sizes) == 262144 and (sizes[0] < min(sizes[1:]) if n == 3 else sizes[0] <= min(sizes[1:]))
     assert len(c4["devices"]) == n and c4["distinct_devices"] == 1 and "rccl_ranks" not in c4       # ranks share the GPU, gloo
     assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True
+    # round 6: the rows-free plans of every rank, gathered and sampled part by part in the pipelined gather's order: same rows
+    assert c4["pipelined_plan_gather_verified"] is True and c4["compute_rows_free_ms"] > 0
     assert c4["plan_gather_ms"] > 0 and c4["steps_per_s_with_plan_gather"] > 0
     if n == 2:                                  # the same with equal blocks
         r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--equal-shards"], UAVAC_BENCH_REHEARSAL="1")
@@ -118,7 +122,9 @@ def test_two_real_gpus_over_rccl_when_the_box_has_them():
     c4 = line["config4"]
     assert c4["gather_verified"] is True and c4["plan_gather_verified"] is True and "overlap_error" not in c4
     assert c4["plan_overlapped_verified"] is True and c4["overlapped_verified"] is True
-    assert c4["rccl_ranks"] == 2 and c4["distinct_devices"] == 2 and len(c4["tick_table"]) == 3
+    assert c4["rccl_ranks"] == 2 and c4["distinct_devices"] == 2 and len(c4["tick_table"]) == 4
+    assert c4["pipelined_plan_gather_verified"] is True and c4["rows_free_overlapped_verified"] is True
+    assert c4["end_to_end"]["form"].startswith("every rank plans ROWS-FREE") and c4["rccl_versions"]["runtime"] > 0
 
 
 def test_ranks_started_by_torch_distributed_run_are_not_launched_again():

@@ -46,6 +46,12 @@ def test_bench_multi_gpu_path_on_real_rccl_at_world_1():
     # round 3: the gather of the plan + re-sampling on the root, verified bit for bit against the gathered rows
     assert c4["plan_gather_verified"] is True and c4["plan_gather_ms"] > 0 and c4["steps_per_s_with_plan_gather"] > 0
     assert c4["plan_overlapped_verified"] is True and "overlap_error" not in c4
+    # round 6: rows-free plans, the pipelined gather (parts on a transfer stream), the rows sampled once -- verified against the
+    # literal row gather, and the job's end-to-end form
+    assert c4["pipelined_plan_gather_verified"] is True and c4["rows_free_overlapped_verified"] is True
+    assert c4["end_to_end"]["form"].startswith("every rank plans ROWS-FREE") and c4["compute_rows_free_ms"] < c4["compute_ms"]
+    assert c4["rccl_versions"]["built_with"] > 0 and c4["rccl_versions"]["runtime"] > 0
+    assert "early" in r.stderr and '"value"' in r.stderr          # the headline on stderr before any collective of config 4
     # round 5: what RCCL and HIP themselves saw -- one rank in the communicator, one named device
     assert c4["rccl_ranks"] == 1 and len(c4["devices"]) == 1 and c4["distinct_devices"] == 1 and c4["devices"][0].startswith("uuid=")
     assert c4["log_pitch"] == 262144 and c4["tick_table"] is None and c4["root_share"] is None      # one rank: nothing to balance

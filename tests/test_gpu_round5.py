@@ -31,28 +31,16 @@ def _missions(B, m):
 def test_create_checks_the_heading_against_the_device_library(nat):
     """uavac_create runs the sampler's heading() and the device library's atan2 -- which the rollout's yaw scan calls -- over 2^16
     operand pairs and every special value and refuses a context when a bit differs (UAVAC_ETOOLCHAIN).  Here: it passes on this
-    toolchain, and creating a context stays cheap with it."""
-    import os
-    import time
+    toolchain; the answer is a property of the build, so only the first context of a process asks (round-5 advice: no wall-clock
+    assertion here)."""
     assert nat.ETOOLCHAIN == -7
     ctx = nat.Context(0)
     ident = ctx.device_identity()
     assert ident.startswith("uuid=") and ";pci=" in ident and "gfx950" in ident
     ctx.close()
 
-    def cost(skip):
-        if skip:
-            os.environ["UAVAC_SKIP_SELFCHECK"] = "1"
-        try:
-            t0 = time.perf_counter()
-            for _ in range(20):
-                nat.Context(0).close()
-            return (time.perf_counter() - t0) / 20
-        finally:
-            os.environ.pop("UAVAC_SKIP_SELFCHECK", None)
-    cost(False)
-    with_check, without = cost(False), cost(True)
-    assert with_check < 0.05 and without < 0.05                  # cheap either way (the check is a 65 680-thread kernel and one copy)
+    for _ in range(3):                                           # later contexts: created and destroyed without the check
+        nat.Context(0).close()
 
 
 def test_clock_probe_reads_a_plausible_shader_clock(eng):

@@ -298,3 +298,39 @@ def test_pipelined_plan_gather_world1_equals_the_one_shot_gather(eng):
             comm.gather_plan(eng.plan_ragged([w[:3] for w in wps[:4]], 3.0, 0.01), parts=True)
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("m", [1, 2, 8, 12, 20])
+def test_both_elimination_orders_against_the_reference_solve_golden(eng, m):
+    """`solve_order` is not a tuning knob: 1 (two-ended, the default at every launch), 0 (one-ended), -1 (opt-in: the faster one
+    by (m, B)) round differently (5e-14).  Each of them sits within 1e-9 (relative, SURVEY 8(c) metric) of the reference's
+    `np.linalg.solve` coefficients on the golden missions, and within 1e-5 of its lstsq ones; -1 is bitwise one of the two, and
+    on a batch past its threshold (m <= 8, 48 missions per SIMD) it is the one-ended kernel."""
+    import torch
+    from conftest import col_err
+    from oracle import minsnap_oracle as mo
+    g = load_golden("synthetic_missions.npz")
+    wps = g[f"m{m}_wp"]
+    got = {}
+    try:
+        for order in (1, 0, -1):
+            eng.ctx.set_option("solve_order", order)
+            p = eng.plan(wps, 3.0, 0.01)
+            got[order] = p.coeffs.clone()
+            co = p.coeffs.cpu().numpy().reshape(-1, 3)
+            assert col_err(co, g[f"m{m}_coeffs_solve"].reshape(-1, 3)) < 1e-9, (m, order)
+            assert col_err(co, g[f"m{m}_coeffs_lstsq"].reshape(-1, 3)) < 1e-5, (m, order)
+        assert torch.equal(got[-1], got[1])                       # 16-32 missions: far below the threshold
+        if m == 8:
+            big = mo.synthetic_missions(49152, 8)
+            full = {}
+            for order in (1, 0, -1):
+                eng.ctx.set_option("solve_order", order)
+                full[order] = eng.plan(big, 3.0, 0.01, rows=False).coeffs
+            assert torch.equal(full[-1], full[0]) and not torch.equal(full[0], full[1])
+            scale = full[1].abs().max()
+            assert float((full[0] - full[1]).abs().max() / scale) < 1e-12
+    finally:
+        eng.ctx.set_option("solve_order", 1)
+    with pytest.raises(Exception):
+        eng.ctx.set_option("solve_order", 2)

@@ -205,7 +205,10 @@ __global__ void heading_selfcheck_kernel(int n_random, int32_t *__restrict__ mis
 __global__ void __launch_bounds__(64) clock_probe_kernel(long long ticks_100mhz, long long *__restrict__ stamps) {
     const long long c0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
     long long r1 = r0;
-    while (r1 - r0 < ticks_100mhz) {
+    // (bounded: a sleep is ~2 k shader cycles, about a microsecond -- at most four naps per 100 MHz tick asked for, so that a
+    // real-time counter that stalls ends the probe with a short window instead of hanging the queue)
+    const long long max_naps = 4 * ticks_100mhz + 1024;
+    for (long long nap = 0; r1 - r0 < ticks_100mhz && nap < max_naps; ++nap) {
         __builtin_amdgcn_s_sleep(32);                      // ~2 k cycles without an instruction issued
         r1 = (long long)__builtin_amdgcn_s_memrealtime();
     }

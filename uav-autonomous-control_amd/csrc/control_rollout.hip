@@ -30,8 +30,10 @@
 #include "minsnap_eval.h"
 #include "minsnap_yaw.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <string>
 
 namespace {
 
@@ -854,8 +856,16 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     const size_t pitch = (LS || LC) ? (ctx->log_pitch > 0 ? (size_t)ctx->log_pitch : (size_t)B) : (size_t)B;
     if (LOGGING && ctx->rollout_align)
         hipLaunchKernelGGL(rollout_align_kernel, dim3(grid), dim3(threads), 0, ctx->stream);
-    if (lds + pad > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad));
+    if (lds + pad > 64 * 1024) {
+        // (an "lds_pad" beyond what a workgroup may have is refused HERE, with the runtime's words, not by a launch that never runs)
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->err = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize = ") + std::to_string(lds + pad) + "): " + hipGetErrorString(e);
+            ctx->launch_rc = UAVAC_EHIP;
+            return;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds + pad, ctx->stream, V, traj, row_offsets, state, istate,
                        B, K, state_log, cmd_log, aabbs, n_obs, n_tiles, pitch, P, late, n_idle);
     auto tf = [](bool v) { return v ? "true" : "false"; };
@@ -865,12 +875,15 @@ void launch_shape(uavac_ctx *ctx, const VehK &V, const double *traj, const int64
     ctx->last_rollout = name;
     // vector registers of that kernel as the loaded code object has them (once per variant): above 256 a SIMD holds ONE
     // wave of it and the launch runs at 0.65x -- a toolchain that crosses the line shows up here and in bench.py's line
-    static int vgprs = -1;
-    if (vgprs < 0) {
+    // (one value per kernel variant, the same from every ctx: an atomic, since distinct ctxs may launch from distinct threads)
+    static std::atomic<int> vgprs{-1};
+    int v = vgprs.load(std::memory_order_relaxed);
+    if (v < 0) {
         hipFuncAttributes fa;
-        vgprs = hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess ? fa.numRegs : 0;
+        v = hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess ? fa.numRegs : 0;
+        vgprs.store(v, std::memory_order_relaxed);
     }
-    ctx->last_rollout_vgprs = vgprs;
+    ctx->last_rollout_vgprs = v;
 }
 
 template <bool LS, bool LC, bool AB>
@@ -956,7 +969,9 @@ int uavac_launch_rollout(uavac_ctx *ctx, const VehK &V, const double *traj, cons
     // LDS, so that the compute wave may run 4 ticks ahead of a stalled store wave, was slower as well: 1.35 vs
     // 1.26 ms -- the hand-over is not what limits the kernel.)  The log rows want B to be a multiple of 16 (128-B lines): B = 65 534 runs at half
     // the rate of B = 65 536 because every 512-B wave store then straddles two partially written lines.
+    ctx->launch_rc = UAVAC_OK;
     launch_flags(ctx, V, traj, row_offsets, state, istate, B, K, state_log, cmd_log, aabbs, n_obs, plan);
+    if (ctx->launch_rc != UAVAC_OK) return ctx->launch_rc;       // (the text is in ctx->err)
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

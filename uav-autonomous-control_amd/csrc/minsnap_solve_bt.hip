@@ -439,7 +439,16 @@ __global__ void __launch_bounds__(TB) minsnap_solve_bt_kernel(const double *__re
 int uavac_launch_solve_bt(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                           int32_t *status, const int64_t *seg_offsets, const int64_t *guard_rows, int64_t guard_capacity,
                           const int32_t *active) {
-    if (ctx->solve_order == 1) return uavac_launch_solve_tw(ctx, wp, times, B, m, coeffs, status, seg_offsets, guard_rows, guard_capacity, active);
+    // WHICH ELIMINATION ORDER.  1 (default): two-ended, whatever the launch -- a mission's coefficients must not depend on how many
+    // other missions share its batch (a rank's shard of a job equals the job's own bits; ragged == uniform; a mission alone == in a
+    // batch: all tested bit for bit), and the two orders round differently (5e-14 relative).  0: one-ended.  -1 (opt-in, round 6):
+    // by the launch -- one-ended where it is the faster kernel, uniform batches of short missions from three quarters of a chip's
+    // worth of lanes on (m <= 8, B >= 48 * SIMDs: 52 against 56-59 us at 65 536 missions of 8 segments, 195 against 213 at 262 144;
+    // below that, and for longer missions at any size, the two-ended form wins: profiles/r05_solve_order_time.jsonl) -- for callers
+    // who take the last-bits dependence on the batch size for those 4-18 us.  Both orders sit equally close to the dense pivoted
+    // solve of the reference (<= 1e-9 on the coefficients against the `solve` goldens, tests/test_gpu_round6.py).
+    const bool two_ended = ctx->solve_order == 1 || (ctx->solve_order < 0 && !(m <= 8 && !seg_offsets && (int64_t)B >= (int64_t)48 * ctx->n_simds));
+    if (two_ended) return uavac_launch_solve_tw(ctx, wp, times, B, m, coeffs, status, seg_offsets, guard_rows, guard_capacity, active);
     const size_t need = (size_t)(m > 1 ? m - 1 : 1) * 28 * (size_t)B;
     if (need > ctx->ws_cap) {
         if (ctx->d_ws) UAVAC_HIP(ctx, hipFree(ctx->d_ws));

@@ -506,14 +506,6 @@ __global__ void __launch_bounds__(TB) minsnap_solve_tw_kernel(const double *__re
 int uavac_launch_solve_tw(uavac_ctx *ctx, const double *wp, const double *times, int B, int m, double *coeffs,
                           int32_t *status, const int64_t *seg_offsets, const int64_t *guard_rows, int64_t guard_capacity,
                           const int32_t *active) {
-    const size_t need = (size_t)(m > 1 ? m - 1 : 1) * 28 * (size_t)B;
-    if (need > ctx->ws_cap) {
-        if (ctx->d_ws) UAVAC_HIP(ctx, hipFree(ctx->d_ws));
-        ctx->d_ws = nullptr;
-        ctx->ws_cap = 0;
-        UAVAC_HIP(ctx, hipMalloc(&ctx->d_ws, sizeof(double) * need));
-        ctx->ws_cap = need;
-    }
     // How the solve is launched (never what it computes: the coefficients are compared bit for bit across these choices).
     //  * missions per wave: 32, 16 or 8 (option "solve_lanes" = 64 / 32 / 16 lanes that carry a mission's half): below a chip's worth
     //    of full waves the kernel is bound by the latency of its dependent chains, and more, emptier waves hide each other's.
@@ -535,6 +527,18 @@ int uavac_launch_solve_tw(uavac_ctx *ctx, const double *wp, const double *times,
     const bool keep = !seg_offsets && !lds_park &&
                       (ctx->solve_keep >= 0 ? ctx->solve_keep != 0 : (ctx->solve_lanes < 0 && waves32 >= ctx->n_simds && lane_knots >= 4));
     const dim3 grid(keep ? waves32 : waves);
+    // The HBM workspace [m - 1][28][B] (rows = a knot's index in its mission) is only needed by the forms that park there: a launch
+    // that parks in LDS never touches it (round-5 advice: 411 MB at B = 262 144, m = 8 were allocated for nothing).
+    if (!lds_park) {
+        const size_t need = (size_t)(m > 1 ? m - 1 : 1) * 28 * (size_t)B;
+        if (need > ctx->ws_cap) {
+            if (ctx->d_ws) UAVAC_HIP(ctx, hipFree(ctx->d_ws));
+            ctx->d_ws = nullptr;
+            ctx->ws_cap = 0;
+            UAVAC_HIP(ctx, hipMalloc(&ctx->d_ws, sizeof(double) * need));
+            ctx->ws_cap = need;
+        }
+    }
 #define UAVAC_SOLVE_LAUNCH(R, P, N, K)                                                                                             \
     do {                                                                                                                            \
         auto kern = minsnap_solve_tw_kernel<R, P, N, K>;                                                                            \

@@ -216,8 +216,8 @@ class Context:
         if rc != OK:
             self._h = _P()
             if rc == ETOOLCHAIN:
-                raise UavacError(rc, "uavac_create refused: this build's heading() and the device library's atan2 differ (see stderr); "
-                                     "rebuild libuavac.so against the installed ROCm")
+                raise UavacError(rc, "uavac_create refused: this build's heading() and the atan2 of the device library it linked differ "
+                                     "(see stderr): heading() in csrc/minsnap_yaw.h must be re-derived for that library")
             raise UavacError(rc, "uavac_create failed: no usable MI355X / HIP runtime (there is no CPU fallback)")
         # contexts are destroyed by an atexit hook registered AFTER torch's HIP runtime came up, i.e. run BEFORE its
         # teardown -- not left to __del__ during interpreter shutdown, when the runtime may already be gone

@@ -33,7 +33,7 @@ def gather_plan(plan, dst: int = 0, group=None, comm: "RcclComm" = None, engine:
                          "batch travels over RCCL only (RcclComm.gather_plan)")
     m = int(plan.m)
     host = lambda t, dt_: torch.as_tensor(np.asarray(t.cpu() if hasattr(t, "cpu") else t)).to(dt_).contiguous()   # noqa: E731
-    co, _ = gather_rows(host(plan.coeffs, torch.float64).reshape(-1, 24), dst, group)
+    co, seg_counts = gather_rows(host(plan.coeffs, torch.float64).reshape(-1, 24), dst, group)
     tm = None
     if plan.times is not None:
         tm, _ = gather_rows(host(plan.times, torch.float64).reshape(-1, 1), dst, group)
@@ -47,9 +47,7 @@ def gather_plan(plan, dst: int = 0, group=None, comm: "RcclComm" = None, engine:
     if engine is not None and parts:
         from .sharding import PIPELINE_SHARES, part_bounds
         shares = PIPELINE_SHARES if parts is True else tuple(parts)
-        b_counts = [torch.zeros_like(n) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(b_counts, torch.tensor([int(plan.B)], dtype=torch.int64), group=group)
-        missions = [int(c.item()) for c in b_counts]
+        missions = [c // m for c in seg_counts]              # (no further collective here: the peers have left already)
         got = engine.plan_from_parts(co.reshape(-1, 8 * m, 3), None if tm is None else tm.reshape(-1, m), sr.reshape(-1, m), m,
                                      plan.velocity, plan.dt, total_rows=sum(counts), sample=False)
         base = np.concatenate([[0], np.cumsum(missions)])

@@ -36,20 +36,26 @@ def shard_bounds(B: int, rank: int, world: int, root_share: float = None, root: 
     return lo, lo + sizes[rank]
 
 
-# One MI355X, measured (round 4: profiles/r04_config_sweep.jsonl, tools/rollout_ab.py, m = 8 .. 12): UAVs in flight on the GPU,
-# us per logged tick, ms of the planning chain per 1 000 missions.  A FALLBACK: `measure_tick_table` measures the same three
-# columns on the GPU at hand in a few tens of milliseconds, and `bench.py --gpus N` does so before it cuts the shards.
-DEFAULT_TICK_TABLE = ((4096, 0.787, 0.027), (16384, 0.792, 0.0180), (24576, 0.843, 0.0170), (32768, 0.857, 0.0163), (35237, 0.876, 0.0163),
-                      (49152, 1.019, 0.0163), (65536, 1.262, 0.0163))
+# One MI355X, measured (round 6: profiles/r06_config4_rows_free_peer.jsonl, r06_config_sweep.jsonl; m = 8 .. 12): UAVs in flight on
+# the GPU, us per logged tick, ms of the planning chain per 1 000 missions WITH rows, the same ROWS-FREE (times, row counts,
+# solve, first headings: Engine.plan(rows=False)).  A FALLBACK: `measure_tick_table` measures the same columns on the GPU at hand in
+# a few tens of milliseconds, and `bench.py --gpus N` does so before it cuts the shards.  (A three-column table -- rounds 4 / 5 --
+# is still taken: rows-free planning is then priced like planning with rows.)
+DEFAULT_TICK_TABLE = ((4096, 0.787, 0.027, 0.0090), (16384, 0.792, 0.0180, 0.0035), (24576, 0.843, 0.0170, 0.0026), (32768, 0.857, 0.0171, 0.0022),
+                      (36864, 0.880, 0.0172, 0.0021), (49152, 1.019, 0.0163, 0.0021), (65536, 1.262, 0.0163, 0.0021))
 
 
 def measure_tick_table(engine: "Engine", segments: int, sizes, velocity: float = 3.0, dt: float = 0.01, ticks: int = 2500,
-                       launches: int = 2, seed: int = 7):
+                       launches: int = 2, seed: int = 7, log_bytes_cap: float = 6e9):
     """What a shard of n missions costs on THIS GPU, for every n in `sizes`: [(n, us per logged tick, ms of the planning chain
-    per 1 000 missions)].  Synthetic missions of the SURVEY 8(d) shape, planned once more after a warm-up, then `launches`
-    logged launches of `ticks` ticks (the first is thrown away; long launches, as the job itself flies them: a launch boundary
-    costs 50-80 us below a full chip).  A few tens of milliseconds per size."""
+    per 1 000 missions with rows, the same rows-free)].  Synthetic missions of the SURVEY 8(d) shape, planned once more after a
+    warm-up, then `launches` (>= 2) logged launches of `ticks` ticks (the first is thrown away; long launches, as the job itself
+    flies them: a launch boundary costs 50-80 us below a full chip).  The log of a launch is capped at `log_bytes_cap` bytes --
+    fewer ticks per launch for a large shard (n = 262 144 would otherwise ask for 68 GB) -- never below 200 ticks.  A few tens of
+    milliseconds per size."""
     torch = engine._torch
+    if int(launches) < 2:
+        raise ValueError("launches >= 2: the first launch is a warm-up and is thrown away")
     rng = np.random.default_rng(seed)
     table = []
     for n in sorted({int(x) for x in sizes if int(x) > 0}):
@@ -58,49 +64,60 @@ def measure_tick_table(engine: "Engine", segments: int, sizes, velocity: float =
         w0 = np.concatenate([rng.uniform(0, 24, (n, 1, 1)), rng.uniform(0, 14, (n, 1, 1)), np.full((n, 1, 1), -3.0)], axis=2)
         wps = np.concatenate([w0, w0 + np.cumsum(rng.uniform(2.5, 3.5, (n, segments, 1)) * d, axis=1)], axis=1)
         plan = engine.plan(wps, velocity, dt)
-        fleet = engine.fleet(plan)
+        free = engine.plan(wps, velocity, dt, rows=False)
+        fleet = engine.fleet(free)                            # plan-fed, as the job flies
         pitch = -(-n // 16) * 16
-        log = torch.empty((ticks, 13, pitch), dtype=torch.float64, device=engine.device)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        k = int(max(200, min(int(ticks), log_bytes_cap // (13 * 8 * pitch))))
+        log = torch.empty((k, 13, pitch), dtype=torch.float64, device=engine.device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         engine.replan(plan)
+        engine.replan(free)
         ev[0].record()
         engine.replan(plan)
         ev[1].record()
-        fleet.reset()
-        fleet.rollout(ticks, state_log=log, log_pitch=pitch)
+        engine.replan(free)
         ev[2].record()
-        for _ in range(launches - 1):
-            fleet.rollout(ticks, state_log=log, log_pitch=pitch)
+        fleet.reset()
+        fleet.rollout(k, state_log=log, log_pitch=pitch)
         ev[3].record()
+        for _ in range(int(launches) - 1):
+            fleet.rollout(k, state_log=log, log_pitch=pitch)
+        ev[4].record()
         torch.cuda.synchronize(engine.device)
-        table.append((n, ev[2].elapsed_time(ev[3]) * 1e3 / ((launches - 1) * ticks), ev[0].elapsed_time(ev[1]) / (n / 1000.0)))
-        del plan, fleet, log
+        table.append((n, ev[3].elapsed_time(ev[4]) * 1e3 / ((int(launches) - 1) * k), ev[0].elapsed_time(ev[1]) / (n / 1000.0),
+                      ev[1].elapsed_time(ev[2]) / (n / 1000.0)))
+        del plan, free, fleet, log
     return table
 
 
 def candidate_shard_sizes(B: int, world: int):
-    """The shard sizes worth measuring before `balanced_root_share` cuts a B-mission job over `world` ranks: half an equal block
-    (about what the root ends up with), an equal block, and a peer's block when the root takes next to nothing."""
+    """The shard sizes worth measuring before `balanced_root_share` cuts a B-mission job over `world` ranks: a small block (what
+    the root ends up with when it samples everybody's rows), half an equal block, an equal block, and a peer's block when the root
+    takes next to nothing."""
     eq = max(1, B // world)
-    return sorted({max(1, eq // 2), eq, min(B, -(-B // max(1, world - 1)))})
+    return sorted({max(1, eq // 8), max(1, eq // 2), eq, min(B, -(-B // max(1, world - 1)))})
 
 
 def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_segment: float = 112.9,
-                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 5.8e12, tick_table=None) -> float:
+                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 5.4e12, tick_table=None, rows_free: bool = True,
+                        first_part_s: float = 0.2e-3) -> float:
     """The share of a B-mission job the gather's root should take so that it finishes with its peers (BASELINE configs[3]).
 
-    A PROJECTION from one-GPU measurements, not a measurement of N GPUs: a peer with n missions plans them and flies `ticks`
-    logged ticks -- both read off `tick_table` = [(n, us per logged tick, ms of planning per 1 000 missions)], as
-    `measure_tick_table` returns it for the GPU at hand (default: `DEFAULT_TICK_TABLE`, round-4 numbers of one MI355X), linear
-    between its points, flat below the first, proportional to n above the last; the root does the same for its own block and,
-    beside it, receives the peers' plans and re-samples their rows (plan gather) or receives the rows themselves -- either way
-    its HBM takes the peers' rows on top of its own log (104 B per UAV tick), so its time is the larger of its flight and of
-    (log + all rows) / the HBM write rate.  Bisection on the share."""
+    A PROJECTION from one-GPU measurements, not a measurement of N GPUs.  A peer with n missions plans them -- rows-free when
+    `rows_free` (round 6: the rows are sampled once, on the root) -- and flies `ticks` logged ticks: both read off `tick_table` =
+    [(n, us per logged tick, ms of planning per 1 000 missions with rows [, rows-free])], as `measure_tick_table` returns it for
+    the GPU at hand (default: `DEFAULT_TICK_TABLE`), linear between its points, flat below the first, proportional to n above
+    the last.  The root does the same for its own block and, beside it, receives the peers' plans and samples EVERYBODY's rows
+    (plan gather; pipelined: it starts `first_part_s` after the job -- the peers' planning + the first part on the links -- and
+    then streams at the rate the sampler writes rows beside a flight, `hbm_write_bytes_per_s`: 20.85 GB in 3.8-3.9 ms on one
+    MI355X, profiles/r06_config4_root_overlap_order.jsonl) or receives the rows themselves over its links.  Its time is the
+    larger of its own plan + flight and of first_part_s + (its log, 104 B per UAV tick, + all rows) / that rate.  Bisection."""
     if world <= 1:
         return 1.0
-    table = sorted((float(n), float(t), float(p)) for n, t, p in (tick_table or DEFAULT_TICK_TABLE))
-    if not table or any(t <= 0 or p <= 0 or n <= 0 for n, t, p in table):
-        raise ValueError("tick_table: [(missions, us per tick, ms of planning per 1000 missions)], all positive")
+    table = sorted(tuple(float(v) for v in row) for row in (tick_table or DEFAULT_TICK_TABLE))
+    if not table or any(len(row) not in (3, 4) or any(v <= 0 for v in row) for row in table):
+        raise ValueError("tick_table: [(missions, us per tick, ms of planning per 1000 missions [, the same rows-free])], all positive")
+    col_plan = 3 if (rows_free and all(len(row) == 4 for row in table)) else 2
     row_bytes = 88.0 * rows_per_segment * segments                       # per mission
 
     def lookup(n, col):
@@ -112,11 +129,11 @@ def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_
         return table[-1][col] * (n / table[-1][0] if col == 1 else 1.0)   # a full chip walks its tiles pass after pass
 
     def own(n):                                                          # plan + flight of n missions, seconds
-        return lookup(n, 2) * 1e-3 * n / 1000.0 + ticks * lookup(n, 1) * 1e-6
+        return lookup(n, col_plan) * 1e-3 * n / 1000.0 + ticks * lookup(n, 1) * 1e-6
 
     def root_time(s):
         n = s * B
-        stream = (n * ticks * 104.0 + B * row_bytes) / hbm_write_bytes_per_s
+        stream = (first_part_s if rows_free else 0.0) + (n * ticks * 104.0 + B * row_bytes) / hbm_write_bytes_per_s
         return max(own(n), stream) if plan_gather else own(n) + (B - n) * row_bytes / (7 * 153e9 * min(1.0, (world - 1) / 7.0))
 
     def peer_time(s):
