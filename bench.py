@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] leg")
     ap.add_argument("--equal-shards", action="store_true", help="configs[3]: equal blocks per rank instead of a smaller block for the gather's root")
+    ap.add_argument("--root-share", type=float, default=None, help="configs[3]: the share of the missions rank 0 (the gather's root) takes, "
+                                                                  "instead of the balance measured at start-up; 0 = it flies nothing")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed diagnostic passes (per-launch table, "
                                                              "flyable-distribution rate)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous + one JSON line, no GPU work (tests of the "
@@ -595,7 +597,9 @@ def main():
         # table goes into the line (`config4.tick_table`).  UAVAC_BENCH_TICK_TABLE='[[n, us_per_tick, plan_ms_per_1000, rows_free_plan_ms_per_1000], ...]'
         # injects a table instead (tests).
         root_share, tick_table = None, None
-        if world > 1 and not args.equal_shards:
+        if world > 1 and args.root_share is not None:
+            root_share = float(args.root_share)
+        elif world > 1 and not args.equal_shards:
             injected = os.environ.get("UAVAC_BENCH_TICK_TABLE")
             if injected:
                 tick_table = [tuple(float(v) for v in row) for row in json.loads(injected)]
@@ -610,10 +614,17 @@ def main():
         lo4, hi4 = shard_bounds(C4_TOTAL, rank, world, root_share, 0)
         B4 = hi4 - lo4
         wps4 = missions(C4_TOTAL, C4_SEGMENTS, lo4, hi4)
-        plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)              # the literal form: this rank's rows are sampled here
-        plan4f = eng.plan(wps4, VELOCITY, DT, rows=False)                       # round 6: no rows here; rank 0 samples them all
-        fleet4 = eng.fleet(plan4)
-        fleet4f = eng.fleet(plan4f)                                             # plan-fed: all a rows-free plan can be
+        if B4 > 0:
+            plan4 = eng.plan(wps4, VELOCITY, DT, placement_trials=1)          # the literal form: this rank's rows are sampled here
+            plan4f = eng.plan(wps4, VELOCITY, DT, rows=False)                   # round 6: no rows here; rank 0 samples them all
+            fleet4 = eng.fleet(plan4)
+            fleet4f = eng.fleet(plan4f)                                         # plan-fed: all a rows-free plan can be
+        else:
+            # The root of an 8-rank job flies NOTHING when the measured table says so (`balanced_root_share` returned 0): sampling
+            # 262 144 missions' rows is as much work as a peer's flight, and a flight beside its own sampler runs a quarter slower.
+            # It takes part in every gather with an empty block.
+            plan4, plan4f = eng.empty_plan(C4_SEGMENTS, VELOCITY, DT), eng.empty_plan(C4_SEGMENTS, VELOCITY, DT, rows=False)
+            fleet4 = fleet4f = None
         pitch4 = -(-B4 // 16) * 16                                                               # rows on 128-byte lines for any B4
         # The 5 000 ticks in as few launches as a 40 GB log allows: ONE at 8 ranks (17-19 GB), two at 2 ranks, five on one GPU.  A
         # launch boundary costs 50-80 us below a full chip (every workgroup waits for the slowest; prologue; aligner): 32 768 UAVs fly
@@ -622,6 +633,8 @@ def main():
         log4 = torch.empty((chunk4, 13, pitch4), dtype=torch.float64, device=dev)
 
         def fly4(fl=fleet4):
+            if fl is None:                                   # (a rank without missions)
+                return
             fl.reset()
             for _ in range(C4_TICKS // chunk4):
                 fl.rollout(chunk4, state_log=log4, log_pitch=pitch4)
@@ -658,10 +671,11 @@ def main():
         # what re-sampling this rank's rows from its plan costs (at N = 1: all 262 144 missions = what the root of the plan
         # gather pays at any N, on top of its own share of the flight), and the two planning chains on their own
         a, b, c, d = ev(), ev(), ev(), ev()
-        eng.sample(plan4)
+        if B4 > 0:
+            eng.sample(plan4)
         eng.replan(plan4f)
         a.record()
-        for _ in range(3):
+        for _ in range(3 if B4 > 0 else 0):
             eng.sample(plan4)
         b.record()
         for _ in range(3):
@@ -675,7 +689,7 @@ def main():
                           "5000 fused ticks (state logged every tick; as few launches as a 40 GB log per rank allows: `ticks_per_launch`), "
                           "trajectories gathered to rank 0",
               "batch_total": C4_TOTAL, "batch_per_gpu": B4, "shard_sizes": sizes4, "root_share": root_share,
-              "tick_table": ([[int(row[0])] + [round(v, 5) for v in row[1:]] for row in tick_table] if tick_table else None),
+              "tick_table": ([[int(row[0])] + [round(v, 7) for v in row[1:]] for row in tick_table] if tick_table else None),
               "tick_table_columns": "missions on the GPU, us per logged tick, ms of planning per 1000 missions with rows, the same rows-free (max over ranks)",
               "log_pitch": pitch4, "ticks_per_launch": chunk4,
               "segments": C4_SEGMENTS, "ticks": C4_TICKS,
@@ -853,7 +867,9 @@ def main():
                                     p, dst=0, stream=st, traj=traj_all, parts=True, known_counts=known), root_flies_first=True),
                                  "rows_free_overlapped_ms", "steps_per_s_rows_free_overlapped", "rows_free_overlapped_verified",
                                  "every rank plans ROWS-FREE (times, row counts, solve, first headings) and flies plan-fed; the plan travels in "
-                                 "parts and rank 0 samples all rows once, part by part, beside its own flight (rank 0 alone sampled)"))
+                                 "parts and rank 0 samples all rows once, part by part" +
+                                 (", beside its own flight" if sizes4[0] > 0 else "; rank 0 flies nothing (shard_sizes[0] = 0: assembling the "
+                                  "trajectories is its share of the job)") + " -- rank 0 alone sampled"))
                     for kind, run, k_ms, k_rate, k_ok, form in variants:
                         over_err, same = None, True
                         try:

@@ -130,8 +130,6 @@ int uavac_clock_probe_dev(uavac_ctx *ctx, int window_us, int64_t *stamps);
  * many 64-row chunks of the sampler's dense yaw column are written together.  "late_handover": -1
  * (default: chosen per launch), 0, 1 = when the compute wave hands a tick's log values to the store
  * wave.  "lds_pad": extra LDS bytes per rollout workgroup (caps the workgroups a CU takes; 0).
- * "plan_blocks": 1 (default: off) .. 8 = uavac_minsnap_plan_dev cuts the batch into that many mission blocks and samples block i
- * on a stream of the ctx's own while block i + 1 is being solved on the caller's (which waits for all of them at the end).
  * "cu_balance": 1 (default) = a logged rollout that needs two or three workgroups on every CU sizes their LDS so
  * that no CU takes more of them than its even share (the dispatcher otherwise gives some CUs three and
  * some one where two each would do), 0 = off.

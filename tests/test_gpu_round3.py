@@ -526,9 +526,12 @@ def test_bench_line_schema_with_extras():
     assert rf["bound"] == "hbm" and 0.5 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert len(rf["per_launch_ms_one_step"]) == 10 and rf["kernel_vgprs"] <= 256
     m = d["minsnap"]
-    assert 0.45 < m["frac_first_allocation"] < 0.85 and m["roofline"]["frac"] == m["frac_first_allocation"]
-    assert "row_buffer_searched_once" not in m
+    # round 6 (round-5 advice): the old keys are on the MEAN of the timed steps again, the median has its own names
+    assert 0.45 < m["roofline"]["frac"] < 0.85 and abs(m["roofline"]["frac"] * m["ms_mean"] - m["roofline"]["frac_median"] * m["ms_median"]) < 1e-9
+    assert m["ms_solve_plus_sample"] == m["ms_mean"] and abs(m["value"] * m["ms_mean"] - m["value_median"] * m["ms_median"]) < 1e-3 * m["value"]
+    assert "row_buffer_searched_once" not in m and "MEAN" in m["statistic"]
     assert m["ms_min"] <= m["ms_median"] <= m["ms_max"] and len(m["ms_per_timed_step"]) == 3 and 0.45 < m["frac_median"] < 0.85
+    assert '"early": true' in r.stderr                                  # the headline went to stderr as soon as it existed
     ck = m["clocked_steps"]
     assert "error" not in ck and len(ck["planning_ms"]) == 8 and all(1.0 < g < 2.6 for g in ck["planning_clock_ghz"])
     assert m["clock_ghz"] == ck["clock_ghz"] and 0.9 < m["leg_to_leg"] < 1.1

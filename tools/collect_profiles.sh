@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, collected on the GPU box into gpurun_out/profiles_<tag>/ (copy what is to be
-# judged into profiles/ afterwards).   bash tools/collect_profiles.sh r05
+# judged into profiles/ afterwards).   bash tools/collect_profiles.sh r06
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 export UAVAC_PROFILE_TAG=$TAG
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/profiles_$TAG

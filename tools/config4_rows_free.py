@@ -54,9 +54,12 @@ def peer(n, reps=7):
     return out
 
 
-def root(n_root, parts, total_rows, traj, reps=6):
-    """rank 0 of the 8-rank job on ONE GPU: its own rows-free plan + flight of n_root UAVs on the current stream, the
-    re-sampling of all 262 144 missions from the (already gathered) plan on a side stream beside it."""
+def root(n_root, parts, total_rows, traj, reps=6, world=8):
+    """rank 0 of the 8-rank job on ONE GPU: its own rows-free plan + flight of n_root UAVs on the current stream (enqueued FIRST:
+    a rollout workgroup that arrives behind the sampler's grid waits for its last wave), the sampling of all 262 144 missions
+    from the (already gathered) plan on a side stream beside it -- in one launch, and in the launches of the pipelined gather:
+    part p (1/16, 3/16, 1/4, 1/2 of every block) of each of `world` ranks' blocks, 4 x world launches."""
+    from uav_ac.sharding import PIPELINE_SHARES, part_bounds, shard_sizes
     co, tm, sr = parts
     wps = missions(C4_TOTAL, m, 0, n_root)
     plan = eng.plan(wps, VELOCITY, DT, rows=False)
@@ -66,49 +69,47 @@ def root(n_root, parts, total_rows, traj, reps=6):
     side = torch.cuda.Stream(device=dev)
     here = torch.cuda.current_stream(dev)
     res = {"leg": "root", "uavs": n_root, "resampled_missions": C4_TOTAL, "rows": total_rows, "row_GB": round(total_rows * 88 / 1e9, 2)}
+    sizes = shard_sizes(C4_TOTAL, world, n_root / C4_TOTAL, 0)
+    base = np.concatenate([[0], np.cumsum(sizes)])
+    bounds = [part_bounds(b, PIPELINE_SHARES) for b in sizes]
 
     def fly():
         eng.replan(plan)
         fleet.reset()
         fleet.rollout(K, state_log=log, log_pitch=pitch)
 
-    def resample(stream):
+    def resample(stream, pipelined):
         with torch.cuda.stream(stream):
-            eng.plan_from_parts(co, tm, sr, m, VELOCITY, DT, total_rows=total_rows, traj=traj)
+            got = eng.plan_from_parts(co, tm, sr, m, VELOCITY, DT, total_rows=total_rows, traj=traj, sample=not pipelined)
+            if pipelined:
+                for p in range(len(PIPELINE_SHARES)):
+                    for r in range(world):
+                        eng.sample_range(got, base[r] + bounds[r][p], base[r] + bounds[r][p + 1])
         eng._bind_stream()
 
-    # "both": which of the two is enqueued first decides everything -- the sampler's grid (262 144 workgroups, six waves of 80
-    # registers per SIMD) never leaves 256 free registers on a SIMD while it has workgroups left, so a rollout workgroup that
-    # arrives behind it waits for its LAST wave; a rollout that is resident first keeps its SIMDs and the sampler fills the rest.
-    for label in ("flight_alone", "resample_alone", "both_resample_first", "both_flight_first", "both_flight_first_hi_prio"):
+    for label in ("flight_alone", "sample_alone_one_launch", "sample_alone_32_launches", "both_sampler_first", "both_flight_first_one_launch",
+                  "both_flight_first_32_launches"):
         ts = []
-        hi = torch.cuda.Stream(device=dev, priority=-1) if label.endswith("hi_prio") else None
         for rep in range(reps):
             torch.cuda.synchronize()
             a, b = ev(), ev()
             a.record()
-            if label == "both_resample_first":
+            pipelined = label.endswith("32_launches")
+            if label == "both_sampler_first":
                 side.wait_stream(here)
-                resample(side)
+                resample(side, False)
                 fly()
                 here.wait_stream(side)
             elif label.startswith("both_flight_first"):
-                side.wait_stream(here)
-                if hi is not None:
-                    hi.wait_stream(here)
-                    with torch.cuda.stream(hi):
-                        fly()
-                    eng._bind_stream()
-                else:
-                    fly()
-                resample(side)
+                fly()
+                # (the plan arrives ~0.2 ms into the job: one wave sleeps that long in front of the sampler)
+                eng.clock_probe_begin(200, stream=side)
+                resample(side, pipelined)
                 here.wait_stream(side)
-                if hi is not None:
-                    here.wait_stream(hi)
             elif label == "flight_alone":
                 fly()
             else:
-                resample(here)
+                resample(here, pipelined)
             b.record()
             torch.cuda.synchronize()
             if rep >= 2:
@@ -130,5 +131,5 @@ if __name__ == "__main__":
     parts = (allp.coeffs.reshape(-1, 8, 3), allp.times.reshape(-1), allp.seg_rows.reshape(-1))
     total_rows = allp.total_rows
     traj = torch.empty((total_rows, 11), dtype=torch.float64, device=dev)
-    for n_root in (2048, 4096, 8192, 10240, 12288, 16384):
+    for n_root in (2048, 4096, 8192, 12288):
         print(json.dumps(root(n_root, parts, total_rows, traj)), flush=True)

@@ -86,8 +86,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
     const double *__restrict__ coeffs, const int32_t *__restrict__ seg_rows, const int64_t *__restrict__ row_offsets, int B,
     int m, double dt, double *__restrict__ traj, const double *__restrict__ aabb, int32_t *__restrict__ hit,
     double *__restrict__ yaw_dense, double *__restrict__ jerk, double *__restrict__ snap, int64_t capacity_rows,
-    int32_t *__restrict__ flags, double *__restrict__ first_yaw_out, const int64_t *__restrict__ seg_offsets, int G, int phase,
-    const int64_t *__restrict__ guard_rows) {
+    int32_t *__restrict__ flags, double *__restrict__ first_yaw_out, const int64_t *__restrict__ seg_offsets, int G, int phase) {
     constexpr int NT = 64 * W;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,8 +104,7 @@ __global__ void __launch_bounds__(64 * W, (W == 16 || DERIVS ? 4 : 6)) minsnap_s
     __shared__ __attribute__((aligned(16))) double heading_poly[kHeadingCoefficients];      // see HeadingFromLds
     int *patch_rows = segn + G;                                             // [G] how many leading rows to patch (0: none)
 
-    // (guard_rows: the plan's row total when this launch samples a sub-range of it -- a refused plan is refused as a whole)
-    if (capacity_rows >= 0 && (guard_rows ? *guard_rows : row_offsets[B]) > capacity_rows) {   // uniform over the launch: nobody writes
+    if (capacity_rows >= 0 && row_offsets[B] > capacity_rows) {             // uniform over the launch: nobody writes
         if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[2], 1);
         return;
     }
@@ -344,7 +342,7 @@ int launch_stream(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows,
     const int phase = (64 - rho) & 63;
     const int groups = (B + G - 1) / G;
     hipLaunchKernelGGL(kern, dim3(groups), dim3(64 * W), lds, ctx->stream, coeffs, seg_rows, row_offsets, B, m, dt, traj, x.aabb,
-                       x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags, x.first_yaw, x.seg_offsets, G, phase, x.guard_rows);
+                       x.hit, x.yaw_dense, x.jerk, x.snap, x.capacity_rows, ctx->d_flags, x.first_yaw, x.seg_offsets, G, phase);
     UAVAC_HIP(ctx, hipGetLastError());
     return UAVAC_OK;
 }

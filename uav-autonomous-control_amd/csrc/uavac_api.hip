@@ -286,10 +286,6 @@ void uavac_destroy(uavac_ctx *ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (hipEvent_t e : ctx->pin_ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : ctx->aux_stream)
-        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    for (hipEvent_t e : ctx->blk_ev)
-        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -351,9 +347,6 @@ int uavac_set_option(uavac_ctx *ctx, const char *name, int value) {
         ctx->idle_waves = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "cu_balance") {
         ctx->cu_balance = value ? 1 : 0;
-    } else if (n == "plan_blocks") {
-        if (value < 1 || value > 8) return uavac_fail(ctx, UAVAC_EINVAL, "plan_blocks is 1 (off) .. 8");
-        ctx->plan_blocks = value;
     } else if (n == "lds_pad") {
         if (value < 0 || value > 120 * 1024) return uavac_fail(ctx, UAVAC_EINVAL, "lds_pad is 0 .. 122880 bytes");
         ctx->lds_pad = value & ~7;
@@ -570,56 +563,16 @@ int uavac_minsnap_plan_dev(uavac_ctx *ctx, const double *wp, int B, int m, doubl
     if (int rc = uavac_launch_row_counts(ctx, wp, B, m, velocity, dt, times_s, seg_rows_s, row_offsets_s)) return rc;
     if (int rc = uavac_launch_plan_commit(ctx, times_s, seg_rows_s, row_offsets_s, B, m, traj_capacity_rows, times, seg_rows,
                                           row_offsets)) return rc;
+    // (Round 6 tried to hide this solve behind the sampler: the batch cut into 2 / 4 / 8 mission blocks, block i sampled on an
+    // auxiliary stream while block i + 1 was being solved.  Bit-identical and SLOWER -- +1.3 % / +13 % / +23 % at 65 536 x 12 --
+    // because a solve wave cannot get onto a SIMD the sampler's grid keeps full: commit 53921dc, profiles/r06_plan_blocks_ab*.jsonl.)
+    if (int rc = uavac_launch_solve_bt(ctx, wp, times_s, B, m, coeffs, status, nullptr, row_offsets_s + B, traj_capacity_rows))
+        return rc;
     SampleExtras x;
     x.yaw_dense = yaw;
     x.first_yaw = first_yaw;
     x.capacity_rows = traj_capacity_rows;         // the sampler refuses (flag 2) instead of overrunning the buffer
-    int nb = ctx->plan_blocks;
-    if (nb > 8) nb = 8;
-    if (nb > 1 && (ctx->sampler_waves <= 1 || B < 64 * nb)) nb = 1;      // (the one-wave sampler has no sub-range guard; tiny batches gain nothing)
-    if (nb <= 1) {
-        if (int rc = uavac_launch_solve_bt(ctx, wp, times_s, B, m, coeffs, status, nullptr, row_offsets_s + B, traj_capacity_rows))
-            return rc;
-        return uavac_launch_sample(ctx, coeffs, seg_rows_s, row_offsets_s, B, m, dt, traj, x);
-    }
-    // BLOCKS (option "plan_blocks", round 6): the solve of block i + 1 on the caller's stream beside the sampling of block i on an
-    // auxiliary stream -- the ~0.1 ms in front of the sampler's write stream shrink to one block's solve.  Same kernels on offset
-    // pointers (row offsets are absolute), same bits; the caller's stream waits for every block at the end.
-    hipStream_t main_stream = ctx->stream;
-    const bool prio = getenv("UAVAC_PLAN_BLOCKS_PRIO") != nullptr;      // experiment: sampler streams at the lowest priority, later solves in the 196-register form
-    for (int i = 0; i < 4; ++i)
-        if (!ctx->aux_stream[i]) {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (prio) UAVAC_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream[i], hipStreamNonBlocking, least));
-            else UAVAC_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking));
-        }
-    for (int i = 0; i < 16; ++i)
-        if (!ctx->blk_ev[i]) UAVAC_HIP(ctx, hipEventCreateWithFlags(&ctx->blk_ev[i], hipEventDisableTiming));
-    x.guard_rows = row_offsets_s + B;
-    int rc = UAVAC_OK;
-    for (int i = 0; i < nb && rc == UAVAC_OK; ++i) {
-        const int b0 = (int)((int64_t)B * i / nb), b1 = (int)((int64_t)B * (i + 1) / nb), n = b1 - b0;
-        const int keep_was = ctx->solve_keep;
-        if (prio && i > 0 && keep_was < 0) ctx->solve_keep = 0;
-        rc = uavac_launch_solve_bt(ctx, wp + (size_t)b0 * (m + 1) * 3, times_s + (size_t)b0 * m, n, m, coeffs + (size_t)b0 * 24 * m,
-                                   status ? status + b0 : nullptr, nullptr, row_offsets_s + B, traj_capacity_rows);
-        ctx->solve_keep = keep_was;
-        if (rc != UAVAC_OK) break;
-        hipStream_t aux = ctx->aux_stream[i & 3];
-        UAVAC_HIP(ctx, hipEventRecord(ctx->blk_ev[i], main_stream));
-        UAVAC_HIP(ctx, hipStreamWaitEvent(aux, ctx->blk_ev[i], 0));
-        SampleExtras xi = x;
-        if (first_yaw) xi.first_yaw = first_yaw + b0;
-        ctx->stream = aux;
-        rc = uavac_launch_sample(ctx, coeffs + (size_t)b0 * 24 * m, seg_rows_s + (size_t)b0 * m, row_offsets_s + b0, n, m, dt, traj, xi);
-        ctx->stream = main_stream;
-        if (rc != UAVAC_OK) break;
-        UAVAC_HIP(ctx, hipEventRecord(ctx->blk_ev[8 + i], aux));
-    }
-    for (int i = 0; i < nb; ++i)                   // whatever was enqueued on an auxiliary stream is waited for, also after a failure
-        (void)hipStreamWaitEvent(main_stream, ctx->blk_ev[8 + i], 0);
-    return rc;
+    return uavac_launch_sample(ctx, coeffs, seg_rows_s, row_offsets_s, B, m, dt, traj, x);
 }
 
 int uavac_minsnap_first_yaw_dev(uavac_ctx *ctx, const double *coeffs, const int32_t *seg_rows, const int64_t *seg_offsets, int B,

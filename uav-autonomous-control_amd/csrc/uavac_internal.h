@@ -43,10 +43,6 @@ struct uavac_ctx {
     int idle_waves = -1;             // tuning: placeholder wave between compute and store wave (0 / 1); -1 = the launcher picks
     int cu_balance = 1;              // tuning: a logged rollout below a full chip asks for as much LDS per workgroup as keeps a CU from taking more workgroups than its even share (0: off)
     int lds_pad = 0;                 // tuning: extra dynamic LDS per rollout workgroup (bytes): caps the workgroups a CU takes
-    int plan_blocks = 1;             // tuning: uavac_minsnap_plan_dev cuts the batch into this many mission blocks and samples block i on an
-                                     // auxiliary stream while block i + 1 is being solved (1 = off: one solve, one sampling)
-    hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // ... its sampler streams (created on first use)
-    hipEvent_t blk_ev[16] = {};      // ... block i solved (8) / block i sampled (8)
     int64_t log_pitch = 0;           // doubles per row of the rollout's logs; 0 = B (option "log_pitch")
     int n_simds = 1024;              // SIMDs of the device (4 per CU): the logged rollout launches one workgroup per SIMD at most
     std::string last_rollout;        // name and template arguments of the rollout kernel launched last (diagnostics)
@@ -192,7 +188,6 @@ struct SampleExtras {
     double *jerk = nullptr;          // [rows][3]
     double *snap = nullptr;          // [rows][3]
     int64_t capacity_rows = -1;      // rows the trajectory buffer holds; < 0: not checked
-    const int64_t *guard_rows = nullptr;    // (streaming sampler) where the plan's row total stands when the launch samples a sub-range; NULL: row_offsets[B]
     const int64_t *seg_offsets = nullptr;   // [B+1] ragged batch (see uavac_launch_row_counts); m is then the maximum
     int64_t total_segments = -1;            // ... and its number of segments (sizes the hit flags)
 };

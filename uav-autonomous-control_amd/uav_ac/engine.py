@@ -266,6 +266,17 @@ class Engine:
             self.check(plan)
         return plan
 
+    def empty_plan(self, m: int, velocity: float = 1.0, dt: float = 0.01, rows: bool = True) -> Plan:
+        """A Plan of NO missions: what a rank holds that plans and flies nothing -- the root of a final gather that only assembles
+        the trajectories -- so that it takes part in the gathers (`RcclComm.gather_rows` / `gather_plan`) with empty blocks."""
+        torch = self._torch
+        kw = dict(device=self.device)
+        m = int(m)
+        z = lambda shape, dtype: torch.zeros(shape, dtype=dtype, **kw)      # noqa: E731
+        return Plan(0, m, float(velocity), float(dt), z((0, m + 1, 3), torch.float64), z((0, m), torch.float64), z((0, m), torch.int32),
+                    z((1,), torch.int64), z((0, 8 * m, 3), torch.float64), z((0,), torch.int32),
+                    z((0, nat.TRAJ_COLS), torch.float64) if rows else None, 0, None, z((0,), torch.float64))
+
     def hbm_peak_bytes_per_s(self) -> float:
         """The device's HBM peak from its own properties (memory clock x bus width x 2, DDR): 8.0e12 on MI355X."""
         p = self._torch.cuda.get_device_properties(self.device)
@@ -329,6 +340,8 @@ class Engine:
         refused on the device AS A WHOLE (flag 2, see `take_flags`): every array of the plan keeps what it held, so the
         previous plan stays consistent and flyable.  A rows-free plan (`plan.traj` is None) runs the rows-free chain: times + row
         counts, offsets, solve, first headings -- nothing to refuse."""
+        if plan.B == 0:
+            return                                               # (`empty_plan`: nothing to plan)
         self._bind_stream()
         cap = 0 if plan.traj is None else int(plan.traj.shape[0])
         self.ctx.call("uavac_minsnap_plan_dev", _ptr(plan.waypoints), plan.B, plan.m, plan.velocity, plan.dt,

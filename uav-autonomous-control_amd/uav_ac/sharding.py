@@ -10,7 +10,8 @@ import numpy as np
 def shard_sizes(B: int, world: int, root_share: float = None, root: int = 0):
     """Missions per rank: contiguous blocks in rank order.  Equal blocks (sizes differ by at most one) unless
     `root_share` is given: then rank `root` -- the rank the trajectories are gathered to -- takes round(root_share * B)
-    missions (at least 1 when B >= world) and the other ranks share the rest equally.  The root of the final gather has
+    missions (at least 1 when B >= world; NONE when root_share is exactly 0: the root then only assembles the trajectories, which
+    at eight ranks is as much work as a peer's flight) and the other ranks share the rest equally.  The root of the final gather has
     extra work (it re-samples or receives everybody's rows while it flies), so its block is made smaller:
     `balanced_root_share` says by how much."""
     B, world = int(B), int(world)
@@ -22,7 +23,7 @@ def shard_sizes(B: int, world: int, root_share: float = None, root: int = 0):
     if not (0.0 <= root_share <= 1.0):
         raise ValueError("root_share is a fraction of the batch")
     n_root = int(round(root_share * B))
-    n_root = max(min(n_root, B), 1 if B >= world else 0)
+    n_root = max(min(n_root, B), 1 if (B >= world and root_share > 0.0) else 0)
     n_root = min(n_root, B - (world - 1) if B >= world else n_root)     # every peer keeps at least one mission
     base, rem = divmod(B - n_root, world - 1)
     peers = [base + (1 if i < rem else 0) for i in range(world - 1)]
@@ -99,8 +100,8 @@ def candidate_shard_sizes(B: int, world: int):
 
 
 def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_segment: float = 112.9,
-                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 5.4e12, tick_table=None, rows_free: bool = True,
-                        first_part_s: float = 0.2e-3) -> float:
+                        plan_gather: bool = True, hbm_write_bytes_per_s: float = 4.8e12, tick_table=None, rows_free: bool = True,
+                        first_part_s: float = 0.2e-3, flight_beside_sampler: float = 1.25) -> float:
     """The share of a B-mission job the gather's root should take so that it finishes with its peers (BASELINE configs[3]).
 
     A PROJECTION from one-GPU measurements, not a measurement of N GPUs.  A peer with n missions plans them -- rows-free when
@@ -109,9 +110,14 @@ def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_
     the GPU at hand (default: `DEFAULT_TICK_TABLE`), linear between its points, flat below the first, proportional to n above
     the last.  The root does the same for its own block and, beside it, receives the peers' plans and samples EVERYBODY's rows
     (plan gather; pipelined: it starts `first_part_s` after the job -- the peers' planning + the first part on the links -- and
-    then streams at the rate the sampler writes rows beside a flight, `hbm_write_bytes_per_s`: 20.85 GB in 3.8-3.9 ms on one
-    MI355X, profiles/r06_config4_root_overlap_order.jsonl) or receives the rows themselves over its links.  Its time is the
-    larger of its own plan + flight and of first_part_s + (its log, 104 B per UAV tick, + all rows) / that rate.  Bisection."""
+    then streams at the rate the sampler writes rows in the pipelined gather's 4 x world launches beside a flight,
+    `hbm_write_bytes_per_s`: 20.85 GB in 4.2 ms alone, 4.4-4.7 ms beside a small flight on one MI355X,
+    profiles/r06_config4_root_pipelined.jsonl) or receives the rows themselves over its links.  Its time is the larger of its own
+    plan + flight -- the flight `flight_beside_sampler` times as long as alone: its log stores queue behind the sampler's write
+    stream, 3.9 -> 4.9-5.4 ms for 2 048 .. 8 192 UAVs -- and of first_part_s + (its log, 104 B per UAV tick, + all rows) / that
+    rate.  Bisection; and when even a small block leaves the root behind its peers the answer is 0.0: the root flies NOTHING
+    and only assembles the trajectories (`shard_sizes` honours an exact 0) -- at eight ranks sampling 262 144 missions' rows is
+    as much work as a peer's 37 450-UAV flight."""
     if world <= 1:
         return 1.0
     table = sorted(tuple(float(v) for v in row) for row in (tick_table or DEFAULT_TICK_TABLE))
@@ -134,7 +140,8 @@ def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_
     def root_time(s):
         n = s * B
         stream = (first_part_s if rows_free else 0.0) + (n * ticks * 104.0 + B * row_bytes) / hbm_write_bytes_per_s
-        return max(own(n), stream) if plan_gather else own(n) + (B - n) * row_bytes / (7 * 153e9 * min(1.0, (world - 1) / 7.0))
+        mine = 0.0 if n < 0.5 else own(n) * (flight_beside_sampler if rows_free else 1.0)
+        return max(mine, stream) if plan_gather else own(n) + (B - n) * row_bytes / (7 * 153e9 * min(1.0, (world - 1) / 7.0))
 
     def peer_time(s):
         return own((1.0 - s) * B / (world - 1))
@@ -148,7 +155,12 @@ def balanced_root_share(B: int, world: int, ticks: int, segments: int, rows_per_
             hi = mid
         else:
             lo = mid
-    return 0.5 * (lo + hi)
+    best = 0.5 * (lo + hi)
+    if plan_gather and rows_free:
+        # a root that flies nothing: no flight to be slowed by its own sampler -- taken when it finishes the job earlier
+        if max(root_time(0.0), peer_time(0.0)) <= max(root_time(best), peer_time(best)) or best * B < 1.0:
+            return 0.0
+    return best
 
 
 # How a pipelined plan gather cuts every rank's block (`RcclComm.gather_plan_begin(parts=...)`): cumulative shares of the
