@@ -55,3 +55,6 @@ SWEEP=launcher python3 tools/half_chip_options.py 8 16384 24576 32768 35237 4915
 python3 tools/config4_chunking.py 32768 2>/dev/null | grep "^{" > "$OUT/${TAG}_config4_chunking.jsonl"
 rm -rf "$OUT/trace/"*results.db "$OUT/pmc_small" "$OUT/pmc_rclock"
 ls -la "$OUT"
+# 10. round 6: config 4 with the rows sampled once -- a peer's chain with rows / rows-free, the root's sampling beside its flight
+python3 tools/config4_rows_free.py 2>/dev/null | grep "^{" > "$OUT/${TAG}_config4_rows_free.jsonl"
+ls -la "$OUT"
