@@ -107,12 +107,14 @@ class RaggedBatch:
     row_offsets: "object"            # (B+1,) i64
     coeffs: "object"                 # (S, 8, 3) f64
     status: "object"                 # (B,) i32, 0 = ok
-    traj: "object"                   # (N, 11) f64
+    traj: "object"                   # (N, 11) f64; None for a rows-free batch
     total_rows: int
     first_yaw: "object"              # (B,) f64
     hit: "object" = None             # (S,) i32 when a cuboid was given
 
     def mission(self, b: int) -> np.ndarray:
+        if self.traj is None:
+            raise ValueError("a rows-free batch (plan_ragged(..., rows=False)) holds no rows")
         ro = self.row_offsets[b:b + 2].cpu().numpy()
         return self.traj[int(ro[0]):int(ro[1])].cpu().numpy().copy()
 
