@@ -632,10 +632,12 @@ def main():
         chunk4 = next(c for c in (5000, 2500, 1000) if c == 1000 or c * 13 * pitch4 * 8 <= 40e9)
         log4 = torch.empty((chunk4, 13, pitch4), dtype=torch.float64, device=dev)
 
-        def fly4(fl=fleet4):
+        def fly4(fl=fleet4, started=None):
             if fl is None:                                   # (a rank without missions)
                 return
             fl.reset()
+            if started is not None:                          # (an event behind the reset: the rollout's launches follow it at once)
+                started.record()
             for _ in range(C4_TICKS // chunk4):
                 fl.rollout(chunk4, state_log=log4, log_pitch=pitch4)
 
@@ -846,7 +848,14 @@ def main():
                             # for its last wave (profiles/r06_config4_root_overlap_order.jsonl: 8.1 ms against 5.1).  The peers
                             # enqueue their sends first: the root waits for them.
                             if root_flies_first and rank == 0:
-                                fly4(fl)
+                                started = torch.cuda.Event() if fl is not None else None
+                                fly4(fl, started)
+                                if started is not None:
+                                    # (host side: begin the gather only when the flight's reset has run -- the rollout kernel is
+                                    # then on the chip within microseconds, whatever the plan's arrival time turns out to be)
+                                    while not started.query():
+                                        pass
+                                    time.sleep(50e-6)
                                 ticket = begin(p, side)
                             else:
                                 ticket = begin(p, side)

@@ -67,6 +67,7 @@ def root(n_root, parts, total_rows, traj, reps=6, world=8):
     pitch = -(-n_root // 16) * 16
     log = torch.empty((K, 13, pitch), dtype=torch.float64, device=dev)
     side = torch.cuda.Stream(device=dev)
+    helpers = [torch.cuda.Stream(device=dev) for _ in range(2)]
     here = torch.cuda.current_stream(dev)
     res = {"leg": "root", "uavs": n_root, "resampled_missions": C4_TOTAL, "rows": total_rows, "row_GB": round(total_rows * 88 / 1e9, 2)}
     sizes = shard_sizes(C4_TOTAL, world, n_root / C4_TOTAL, 0)
@@ -81,20 +82,34 @@ def root(n_root, parts, total_rows, traj, reps=6, world=8):
     def resample(stream, pipelined):
         with torch.cuda.stream(stream):
             got = eng.plan_from_parts(co, tm, sr, m, VELOCITY, DT, total_rows=total_rows, traj=traj, sample=not pipelined)
-            if pipelined:
+            if pipelined == 1:
                 for p in range(len(PIPELINE_SHARES)):
                     for r in range(world):
                         eng.sample_range(got, base[r] + bounds[r][p], base[r] + bounds[r][p + 1])
+        if pipelined == 3:                                    # the ranges of a part over three streams (what RcclComm._sample_parts does)
+            lanes = [stream] + helpers
+            ready = torch.cuda.Event(); ready.record(stream)
+            for h in helpers:
+                h.wait_event(ready)
+            k = 0
+            for p in range(len(PIPELINE_SHARES)):
+                for r in range(world):
+                    if bounds[r][p + 1] > bounds[r][p]:
+                        with torch.cuda.stream(lanes[k % 3]):
+                            eng.sample_range(got, base[r] + bounds[r][p], base[r] + bounds[r][p + 1])
+                        k += 1
+            for h in helpers:
+                stream.wait_stream(h)
         eng._bind_stream()
 
-    for label in ("flight_alone", "sample_alone_one_launch", "sample_alone_32_launches", "both_sampler_first", "both_flight_first_one_launch",
-                  "both_flight_first_32_launches"):
+    for label in ("flight_alone", "sample_alone_one_launch", "sample_alone_32_launches", "sample_alone_32_launches_3_streams", "both_sampler_first",
+                  "both_flight_first_one_launch", "both_flight_first_32_launches", "both_flight_first_32_launches_3_streams"):
         ts = []
         for rep in range(reps):
             torch.cuda.synchronize()
             a, b = ev(), ev()
             a.record()
-            pipelined = label.endswith("32_launches")
+            pipelined = 3 if label.endswith("3_streams") else (1 if label.endswith("32_launches") else 0)
             if label == "both_sampler_first":
                 side.wait_stream(here)
                 resample(side, False)

@@ -224,18 +224,43 @@ class RcclComm:
             with torch.cuda.stream(stream):
                 stream.wait_event(events[0])
                 gathered = e.plan_from_parts(co, tm, sr, m, plan.velocity, plan.dt, total_rows=sum(row_counts), traj=traj, sample=False)
-                base = np.concatenate([[0], np.cumsum(missions)])
-                for p in range(len(shares)):
-                    if p:
-                        stream.wait_event(events[p])
-                    for r in range(self.world):
-                        e.sample_range(gathered, base[r] + bounds[r][p], base[r] + bounds[r][p + 1])
-                for t in (co, tm, sr):                        # allocated under the transfer stream, read by the sampler on `stream`
-                    if t is not None:
-                        t.record_stream(stream)
+            base = np.concatenate([[0], np.cumsum(missions)])
+            self._sample_parts(gathered, [[(base[r] + bounds[r][p], base[r] + bounds[r][p + 1]) for r in range(self.world)]
+                                          for p in range(len(shares))], events, stream, (co, tm, sr))
         stream.wait_stream(xfer)                              # whoever waits for `stream` (gather_finish) has waited for the transfers
         e._bind_stream()                                      # back on the caller's stream
         return (stream, gathered, row_counts, (plan, None))
+
+    def _sample_parts(self, gathered, ranges_by_part, events, stream, inputs):
+        """The root's sampling of a pipelined gather: part p's ranges (one per rank) behind events[p].  The ranges of one part go
+        to `stream` and to two helper streams in turn: launches on ONE stream run one after the other, and every launch ends with
+        a tail in which the chip drains -- 32 launches in a row take 4.2 ms for config 4's 20.85 GB against 3.9 ms for one launch;
+        spread over three streams the tails of one launch lie under the body of the next.  `stream` waits for the helpers at
+        the end: whoever waits for `stream` has waited for every row."""
+        e, torch = self.engine, self.engine._torch
+        if getattr(self, "_helpers", None) is None:
+            self._helpers = [torch.cuda.Stream(device=e.device) for _ in range(2)]
+        lanes = [stream] + self._helpers
+        ready = torch.cuda.Event()
+        ready.record(stream)                                  # row offsets laid out (plan_from_parts ran on `stream`)
+        for h in self._helpers:
+            h.wait_event(ready)
+        k = 0
+        for p, ranges in enumerate(ranges_by_part):
+            for s_ in lanes:
+                s_.wait_event(events[p])
+            for b0, b1 in ranges:
+                if b1 > b0:
+                    with torch.cuda.stream(lanes[k % len(lanes)]):
+                        e.sample_range(gathered, b0, b1)
+                    k += 1
+        for h in self._helpers:
+            stream.wait_stream(h)
+        for t in list(inputs) + [gathered.row_offsets, gathered.first_yaw, gathered.traj]:
+            if t is not None:                                 # allocated under one stream, used by the sampler on all three
+                for s_ in lanes:
+                    t.record_stream(s_)
+        e._bind_stream()
 
     def gather_finish(self, ticket):
         """Wait for a gather started with `gather_rows_begin` / `gather_plan_begin` -> (result on dst | None, counts)."""
