@@ -334,3 +334,30 @@ def test_both_elimination_orders_against_the_reference_solve_golden(eng, m):
         eng.ctx.set_option("solve_order", 1)
     with pytest.raises(Exception):
         eng.ctx.set_option("solve_order", 2)
+
+
+def test_rows_free_ragged_batches_fly_and_travel_like_full_ones(eng):
+    """A ragged batch planned rows-free (plan_ragged(rows=False)): a fleet on it logs what the fleet on the full batch logs, and the
+    plan gather (world 1, RCCL) turns it into the full batch's rows on the root -- the rows were never sampled where it was planned."""
+    import torch
+    from uav_ac import _native as nat
+    from uav_ac.fleet import RcclComm
+    rng = np.random.default_rng(66)
+    missions = _fuzz_missions(rng, 300, vertical=0.2)
+    full = eng.plan_ragged(missions, 2.5, 0.01)
+    free = eng.plan_ragged(missions, 2.5, 0.01, rows=False)
+    a, _ = eng.fleet(full, from_plan=True).rollout(900, state_log=True)
+    b, _ = eng.fleet(free).rollout(900, state_log=True)
+    c, _ = eng.fleet(full, from_plan=False).rollout(900, state_log=True)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    with pytest.raises(ValueError):
+        free.mission(0)
+    buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+    eng.ctx.call("uavac_comm_unique_id", buf)
+    comm = RcclComm(eng, unique_id=bytes(buf.raw), world=1, rank=0)
+    try:
+        got, counts = comm.gather_plan(free, dst=0)
+        assert counts == [full.total_rows] and torch.equal(got.traj, full.traj) and torch.equal(got.first_yaw, full.first_yaw)
+        assert torch.equal(got.row_offsets, full.row_offsets) and torch.equal(got.coeffs, full.coeffs)
+    finally:
+        comm.close()
