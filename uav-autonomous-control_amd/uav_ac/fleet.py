@@ -15,8 +15,6 @@ from __future__ import annotations
 
 import ctypes as C
 
-import numpy as np
-
 from . import _native as nat
 
 _P = C.c_void_p
