@@ -605,10 +605,22 @@ def main():
                 tick_table = [tuple(float(v) for v in row) for row in json.loads(injected)]
             else:
                 sizes_c = candidate_shard_sizes(C4_TOTAL, world)
-                mine = measure_tick_table(eng, C4_SEGMENTS, sizes_c, VELOCITY, DT)
+                # (a rank whose measurement fails must not leave the others waiting in the reduction: every rank contributes a
+                # table of the agreed shape, a failed one as +inf, and any +inf sends ALL ranks to the built-in table)
+                try:
+                    mine = measure_tick_table(eng, C4_SEGMENTS, sizes_c, VELOCITY, DT)
+                    if [row[0] for row in mine] != sizes_c:
+                        raise RuntimeError("tick table of another shape")
+                except Exception as exc:
+                    print(f"bench.py: rank {rank}: measuring the tick table failed ({type(exc).__name__}: {exc}); built-in table", file=sys.stderr, flush=True)
+                    mine = [(n, float("inf"), float("inf"), float("inf")) for n in sizes_c]
+                    torch.cuda.empty_cache()
                 t = torch.tensor([list(row[1:]) for row in mine], dtype=torch.float64, device=cdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tick_table = [(row[0],) + tuple(float(v) for v in cols) for row, cols in zip(mine, t.cpu().tolist())]
+                if bool(torch.isinf(t).any()):
+                    tick_table = None                      # balanced_root_share falls back to DEFAULT_TICK_TABLE
+                else:
+                    tick_table = [(row[0],) + tuple(float(v) for v in cols) for row, cols in zip(mine, t.cpu().tolist())]
             root_share = balanced_root_share(C4_TOTAL, world, C4_TICKS, C4_SEGMENTS, tick_table=tick_table)
         sizes4 = shard_sizes(C4_TOTAL, world, root_share, 0)
         lo4, hi4 = shard_bounds(C4_TOTAL, rank, world, root_share, 0)
