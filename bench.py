@@ -287,6 +287,13 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 or os.environ.get("UAVAC_BENCH_FORCE_DIST") == "1":
+        # HIP maps a process's streams round-robin onto a few hardware queues (default 4), and two streams that share a queue run
+        # one after the other.  The config-4 leg of a multi-rank run uses a handful of them at once on the root -- its flight, the
+        # transfers, the sampling launches -- and a collision there serialises flight and sampling (8.4 instead of 5.1 ms on one
+        # MI355X, profiles/r06_hw_queue_collisions.txt).  Must be set before the HIP runtime comes up; ranks started by a launcher
+        # set it themselves right here, children of the self-launcher inherit it.  (N = 1: the environment is left as it is.)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))          # no launcher around us: be the launcher (before any GPU call)
     if args.launch_check:
@@ -705,7 +712,7 @@ def main():
               "batch_total": C4_TOTAL, "batch_per_gpu": B4, "shard_sizes": sizes4, "root_share": root_share,
               "tick_table": ([[int(row[0])] + [round(v, 7) for v in row[1:]] for row in tick_table] if tick_table else None),
               "tick_table_columns": "missions on the GPU, us per logged tick, ms of planning per 1000 missions with rows, the same rows-free (max over ranks)",
-              "log_pitch": pitch4, "ticks_per_launch": chunk4,
+              "log_pitch": pitch4, "ticks_per_launch": chunk4, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
               "segments": C4_SEGMENTS, "ticks": C4_TICKS,
               "rows_rank0": plan4.total_rows, "compute_ms": c4_compute * 1e3,
               "steps_per_s_compute_only": C4_TOTAL * C4_TICKS / c4_compute, "rollout_kernel": kernel4,

@@ -118,7 +118,7 @@ def root(n_root, parts, total_rows, traj, reps=6, world=8):
             elif label.startswith("both_flight_first"):
                 fly()
                 # (the plan arrives ~0.2 ms into the job: one wave sleeps that long in front of the sampler)
-                eng.clock_probe_begin(200, stream=side)
+                eng.clock_probe_begin(int(os.environ.get("ROOT_DELAY_US", "200")), stream=side)
                 resample(side, pipelined)
                 here.wait_stream(side)
             elif label == "flight_alone":
@@ -146,5 +146,5 @@ if __name__ == "__main__":
     parts = (allp.coeffs.reshape(-1, 8, 3), allp.times.reshape(-1), allp.seg_rows.reshape(-1))
     total_rows = allp.total_rows
     traj = torch.empty((total_rows, 11), dtype=torch.float64, device=dev)
-    for n_root in (2048, 4096, 8192, 12288):
+    for n_root in [int(x) for x in os.environ.get("ROOT_SIZES", "2048,4096,8192,12288").split(",")]:
         print(json.dumps(root(n_root, parts, total_rows, traj)), flush=True)
